@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the KNN hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): statistical_outlier_removal k=16 (std_mul 1.0) + PCA normals
+k=16 on a synthetic uniform-random cloud, 1 M points per GPU, inputs resident in HBM.  A step is
+one full pass: [all-gather of the column shards when N > 1] -> index build -> fused neighbour
+search + SOR mean + normals -> [all-gather of the means] -> global threshold -> inlier mask.
+N > 1 shards the queries of one N x 1 M-point cloud over the ranks (weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the neighbour-search kernel with HIP events
+recorded on its own stream; `cpu_baseline` times the CPU oracle (a C port of the reference
+algorithms, reference threading: SOR single-threaded, normals on all cores) on the same cloud.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pointclouds-rs_amd"))
+
+POINTS_PER_GPU = 1_000_000
+K_SOR = 16
+K_NRM = 16
+STD_MUL = 1.0
+BYTES_PER_POINT = 29  # 12 B xyz read + 4 B mean + 1 B mask + 12 B normal written
+HBM_PEAK_GBPS = 8000.0
+
+
+def cpu_baseline(x, y, z):
+    """The oracle (test infrastructure) as the CPU leg: never part of the measured GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi
+
+    o = oracle_ffi.load()
+    cores = o.max_threads()
+    t0 = time.perf_counter()
+    o.sor(x, y, z, K_SOR, STD_MUL, algo=1, threads=1)          # the reference's SOR loop is sequential
+    t1 = time.perf_counter()
+    o.normals(x, y, z, K_NRM, (0.0, 0.0, 0.0), algo=1, threads=cores)  # rayon par_iter
+    t2 = time.perf_counter()
+    n = len(x)
+    return {
+        "value": n / (t2 - t0) / 1e6,
+        "unit": "Mpoints/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"the whole {n}-point cloud once: SOR k={K_SOR} on 1 thread ({t1 - t0:.2f} s, as the "
+                  f"reference) + normals k={K_NRM} on {cores} threads ({t2 - t1:.2f} s); exact uniform-grid "
+                  "search in place of the kiddo KD-tree",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=POINTS_PER_GPU, help="points per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--icp-iters", type=int, default=50, help="ICP iterations for the side metric (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback of the product path")
+    torch.cuda.set_device(local_rank)
+
+    from pointclouds_rs import _ffi, synth
+    from pointclouds_rs.dist import Collectives, HipEngine, shard_range, sor_normals_sharded
+
+    engine = HipEngine(local_rank)
+    coll = Collectives(dist)
+    n_total = args.points * world
+    begin, end = shard_range(n_total, world, rank)
+    # one cloud of n_total points at unit density: side 100 * world^(1/3); each rank generates
+    # only its own index range (the generator is a pure function of the index)
+    side = 100.0 * (n_total / 1_000_000.0) ** (1.0 / 3.0)
+    full_host = None
+    cols = []
+    for axis in range(3):
+        u = synth.uniform01(42, n_total, axis)[begin:end] if world > 1 else synth.uniform01(42, n_total, axis)
+        cols.append((u * np.float32(side)).astype(np.float32))
+    if rank == 0 and world == 1:
+        full_host = cols
+    shard = [engine.from_numpy(c) for c in cols]
+    nq = end - begin
+    outputs = dict(mean=engine.empty(nq), keep=engine.empty(nq, "uint8"), nx=engine.empty(nq),
+                   ny=engine.empty(nq), nz=engine.empty(nq))
+
+    def step():
+        return sor_normals_sharded(engine, coll, shard, n_total, K_SOR, STD_MUL, K_NRM,
+                                   (0.0, 0.0, 0.0), outputs)
+
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    coll.barrier()
+    engine.timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    coll.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = engine.timing_read()
+    engine.timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=engine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total * args.steps / elapsed / 1e6
+    avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+    achieved = BYTES_PER_POINT * nq / avg_kernel_s / 1e9 if launches else 0.0
+
+    icp_line = None
+    if args.icp_iters > 0 and rank == 0:
+        icp_line = bench_icp(engine, synth, args.icp_iters)
+
+    if rank == 0:
+        out = {
+            "metric": "Mpoints/sec through SOR k=16 + normals on 1M-pt cloud; ICP iters/sec",
+            "value": value,
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"SOR k={K_SOR} std_mul={STD_MUL} + normals k={K_NRM}, uniform-random cloud, "
+                            f"{args.points} points per GPU ({n_total} total), queries sharded over ranks",
+                "points_per_gpu": args.points,
+                "n_keep_rank0": int(res["n_keep"]),
+                "threshold": res["thr"],
+                "search_stats_rank0": dict(zip(("grid_tile", "grid_ring", "brute"), res["stats"])),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel": "neighbour search + fused SOR mean / PCA normal",
+                "kernel_ms_avg": avg_kernel_s * 1e3,
+                "kernel_launches": launches,
+                "algorithmic_bytes_per_launch": BYTES_PER_POINT * nq,
+                "note": "the kernel is VALU-bound (distance + top-k selection), not HBM-bound: "
+                        "29 B/pt of algorithmic traffic against thousands of lane-ops per point",
+            },
+        }
+        if icp_line:
+            out["icp"] = icp_line
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(*full_host)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_icp(engine, synth, iters):
+    """configs[2]: point-to-plane ICP, two 100 K-point scans, tolerance 0 so every iteration runs."""
+    import numpy as np
+    import torch
+
+    from pointclouds_rs import _ffi
+
+    n = 100_000
+    tgt_h = synth.hemisphere(n, 99, 5.0)
+    R = synth.rot_z(0.05)
+    t = np.array([0.3, -0.2, 0.1], dtype=np.float32)
+    P = np.stack(tgt_h, 1)
+    S = (P @ R.T + t).astype(np.float32)
+    tgt = [engine.from_numpy(c) for c in tgt_h]
+    src = [engine.from_numpy(np.ascontiguousarray(S[:, a])) for a in range(3)]
+    nrm = [engine.empty(n) for _ in range(3)]
+    ix = engine.build_index(*tgt, 16)
+    engine.sor_normals_range(ix, 0, n, 0, 16, (0.0, 0.0, 0.0), None, *nrm)
+    engine.destroy_index(ix)
+    h = engine.icp_create(src, tgt, nrm)
+    engine.icp_run(h, _ffi.ICP_POINT_TO_PLANE, 3, 0.0, float("inf"))  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = engine.icp_run(h, _ffi.ICP_POINT_TO_PLANE, iters, 0.0, float("inf"))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    engine.icp_destroy(h)
+    return {
+        "workload": f"point-to-plane ICP, {n} x {n} points (hemisphere r=5, Rz(0.05)+t), {iters} iterations, tolerance 0",
+        "iters_per_sec": res.num_iterations / dt,
+        "ms_per_iter": dt / max(res.num_iterations, 1) * 1e3,
+        "rmse": res.rmse,
+        "fitness": res.fitness,
+        "num_iterations": int(res.num_iterations),
+    }
+
+
+if __name__ == "__main__":
+    main()

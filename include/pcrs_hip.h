@@ -1,0 +1,272 @@
+/*
+ * pcrs_hip.h — C-ABI of libpcrs_hip.so, the MI355X (gfx950) implementation of
+ * the pointclouds-rs per-point KNN hot path.
+ *
+ * The reference has no FFI of its own: the path sits behind safe-Rust `pub fn`s
+ * in crates that `#![forbid(unsafe_code)]`.  Each entry point below cites the
+ * Rust function (file:line, relative to the reference checkout) it stands in
+ * for; a `pointclouds-hip-sys` crate binds exactly these symbols.
+ *
+ * Conventions
+ *  - Every function returns PCRS_OK (0) or a negative PCRS_ERR_* code and never
+ *    unwinds across the boundary.  pcrs_last_error() gives the message of the
+ *    last failure on that context.
+ *  - Point clouds are structure-of-arrays f32 columns (x[], y[], z[]), exactly
+ *    `PointCloud { x, y, z: Vec<f32> }` (crates/core/src/cloud.rs:3-11), so a
+ *    Rust caller passes `Vec::as_ptr()` with no repacking.
+ *  - Functions WITHOUT the `_dev` suffix take HOST pointers, copy in/out and
+ *    return when the outputs are complete.  The caller owns every buffer; the
+ *    library keeps no host pointer after return.
+ *  - Functions WITH the `_dev` suffix take DEVICE pointers (hipMalloc'd memory
+ *    on the context's device), run on the context's stream and synchronise
+ *    that stream only where a scalar is returned to the host.
+ *  - A context is bound to one device and one stream and is not thread-safe;
+ *    use one context per GPU (one per process in multi-GPU jobs).
+ *  - Neighbour order is ascending squared distance, then DESCENDING point
+ *    index among equidistant points (kiddo's own tie order is traversal
+ *    dependent; this is the order under which the reference test
+ *    icp.rs:345-368 passes as written); a point with a non-finite coordinate is
+ *    never a neighbour; a query with a non-finite coordinate has no neighbours
+ *    (kdtree.rs:65).
+ */
+#ifndef PCRS_HIP_H
+#define PCRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCRS_OK 0
+#define PCRS_ERR_INVALID_ARG (-1)
+#define PCRS_ERR_HIP (-2)
+#define PCRS_ERR_OOM (-3)
+/* IcpPlaneError::NormalsMismatch, crates/registration/src/icp_plane.rs:27-32,101-107 */
+#define PCRS_ERR_NORMALS_MISMATCH (-4)
+
+#define PCRS_NO_INDEX 0xFFFFFFFFu
+
+#define PCRS_ICP_POINT_TO_POINT 0
+#define PCRS_ICP_POINT_TO_PLANE 1
+
+/* search strategy of an index (pcrs_index_build*): */
+#define PCRS_ALGO_AUTO 0  /* uniform grid when the cloud is large enough, else brute force */
+#define PCRS_ALGO_BRUTE 1 /* LDS-tiled brute force over the whole cloud */
+#define PCRS_ALGO_GRID 2  /* uniform-grid pruned tiles with exact fallback */
+
+typedef struct pcrs_ctx pcrs_ctx;
+typedef struct pcrs_index pcrs_index;
+typedef struct pcrs_icp pcrs_icp;
+
+/* IcpResult + RigidTransform, crates/registration/src/icp.rs:7-11,111-118 */
+typedef struct pcrs_icp_result {
+    float rotation[9]; /* row-major 3x3 */
+    float translation[3];
+    float fitness;
+    float rmse;
+    int32_t converged;
+    uint32_t num_iterations;
+} pcrs_icp_result;
+
+/* Number of doubles pcrs_icp_accumulate* produces (layout documented there). */
+#define PCRS_ICP_NSUMS 32
+
+/* ---------------------------------------------------------------- context */
+
+/* Creates a context on HIP device `device` with its own stream. */
+int pcrs_ctx_create(int device, pcrs_ctx **out);
+/* Uses `hip_stream` (a hipStream_t, e.g. torch's current stream) from now on. */
+int pcrs_ctx_set_stream(pcrs_ctx *ctx, void *hip_stream);
+void pcrs_ctx_destroy(pcrs_ctx *ctx);
+const char *pcrs_last_error(const pcrs_ctx *ctx);
+int pcrs_ctx_synchronize(pcrs_ctx *ctx);
+/* Library version string and the GPU architecture the kernels were built for. */
+const char *pcrs_version(void);
+
+/* ------------------------------------------------- spatial index (KdTree) */
+
+/* KdTree::build — crates/spatial/src/kdtree.rs:25-44.
+ * Builds the device-resident search structure over m points.  `k_hint` is the
+ * neighbour count the index will mostly be asked for (sizes the grid cells;
+ * 0 = default).  The _dev form keeps the column pointers, which must stay
+ * valid and unchanged until pcrs_index_destroy; the host form uploads a copy. */
+int pcrs_index_build(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t m,
+                     uint32_t k_hint, int algo, pcrs_index **out);
+int pcrs_index_build_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                         size_t m, uint32_t k_hint, int algo, pcrs_index **out);
+void pcrs_index_destroy(pcrs_index *index);
+/* KdTree::len — kdtree.rs:47-49 */
+size_t pcrs_index_len(const pcrs_index *index);
+
+/* Batched KdTree::knn / knn_indices — kdtree.rs:64-96.
+ * For each of the n queries writes up to k neighbours, ascending:
+ *   idx  [n*k] point indices, PCRS_NO_INDEX padded
+ *   dist [n*k] Euclidean distances sqrt(d2) (kdtree.rs:76), NaN padded; nullable
+ *   count[n]   neighbours found = min(k, finite points), 0 for a non-finite
+ *              query, k == 0 or an empty index; nullable */
+int pcrs_knn_batch(pcrs_index *index, const float *qx, const float *qy, const float *qz, size_t n,
+                   uint32_t k, uint32_t *idx, float *dist, uint32_t *count);
+int pcrs_knn_batch_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
+                       size_t n, uint32_t k, uint32_t *didx, float *ddist, uint32_t *dcount);
+
+/* Batched count of KdTree::radius_search results — kdtree.rs:105-135 (points
+ * with d2 <= radius*radius, the query itself included when it is in the cloud).
+ * count[n]; a non-positive or non-finite radius or a non-finite query gives 0. */
+int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const float *qz,
+                      size_t n, float radius, uint32_t *count);
+int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
+                          size_t n, float radius, uint32_t *dcount);
+
+/* ------------------------------------------- statistical_outlier_removal */
+
+/* The per-point loop of statistical_outlier_removal —
+ * crates/filters/src/statistical_outlier.rs:19-39: mean Euclidean distance to
+ * the k nearest other points ((k+1)-NN, first dropped); +inf for a non-finite
+ * point.  Self-query over points [q_begin, q_begin+q_count) of the indexed
+ * cloud; mean[q_count].  Requires k >= 1. */
+int pcrs_sor_mean_dist_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
+                           float *dmean);
+
+/* Global threshold mu + std_mul*sigma over the finite means, with the
+ * reference's sequential-f32 summation order — statistical_outlier.rs:43-62.
+ * *has_finite = 0 (and *thr = NaN) when no mean is finite (:49-51). */
+int pcrs_sor_threshold_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul, float *thr,
+                           int *has_finite);
+
+/* keep[i] = mean[i] <= thr — statistical_outlier.rs:64-66.  *n_keep nullable. */
+int pcrs_sor_mask_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float thr, uint8_t *dkeep,
+                      size_t *n_keep);
+
+/* statistical_outlier_removal(cloud, k, std_mul) — statistical_outlier.rs:4-69.
+ * keep[n] is the inlier mask (the caller applies PointCloud::select,
+ * crates/core/src/cloud.rs:103-140); *n_keep the survivor count; *thr_out
+ * (nullable) the threshold, NaN when none was computed.  Edge cases as the
+ * reference: n == 0 or k == 0 keeps nothing, n == 1 keeps the point.
+ * mean_out (nullable) receives the n per-point mean distances when computed. */
+int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n, uint32_t k,
+             float std_mul, uint8_t *keep, size_t *n_keep, float *thr_out, float *mean_out);
+
+/* -------------------------------------------------------- estimate_normals */
+
+/* estimate_normals_with_viewpoint — crates/normals/src/estimate.rs:19-124,
+ * eigen-solve :139-238.  Self-query over points [q_begin, q_begin+q_count);
+ * nx/ny/nz[q_count].  Requires k >= 1. */
+int pcrs_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
+                     const float viewpoint[3], float *dnx, float *dny, float *dnz);
+
+/* One neighbour search feeding both consumers: SOR means from ranks 1..k_sor of
+ * the (k_sor+1)-NN list, normals from ranks 0..k_normals-1.  Either output
+ * group may be NULL to skip it. */
+int pcrs_sor_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k_sor,
+                         uint32_t k_normals, const float viewpoint[3], float *dmean, float *dnx,
+                         float *dny, float *dnz);
+
+/* estimate_normals_with_viewpoint on host buffers.  k == 0 or n == 0 writes
+ * nothing (the reference returns empty vectors, estimate.rs:25-31). */
+int pcrs_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                 uint32_t k, const float viewpoint[3], float *nx, float *ny, float *nz);
+
+/* SOR + normals of one cloud with a single upload and index build. */
+int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                     uint32_t k_sor, float std_mul, uint32_t k_normals, const float viewpoint[3],
+                     uint8_t *keep, size_t *n_keep, float *thr_out, float *nx, float *ny,
+                     float *nz);
+
+/* ------------------------------------------------------------ registration */
+
+/* apply_transform — crates/registration/src/icp.rs:39-47,77-92: p' = R p + t,
+ * row-major R, additions left to right, no fused multiply-add. */
+int pcrs_apply_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                         const float rotation[9], const float translation[3], float *ox,
+                         float *oy, float *oz);
+int pcrs_apply_transform_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                             size_t n, const float rotation[9], const float translation[3],
+                             float *dox, float *doy, float *doz);
+
+/* RigidTransform::compose — icp.rs:52-73: apply (ra,ta) first, then (rb,tb). */
+void pcrs_compose(const float ra[9], const float ta[3], const float rb[9], const float tb[3],
+                  float rout[9], float tout[3]);
+
+/* find_correspondences — crates/registration/src/correspondence.rs:16-39,
+ * dense form: tgt_idx[n] is the nearest target index or PCRS_NO_INDEX where the
+ * source point has no correspondence (dist > max_distance, non-finite point,
+ * empty target); dist[n] its Euclidean distance (NaN where none).
+ * *n_corr (nullable) counts the correspondences. */
+int pcrs_find_correspondences(pcrs_index *target, const float *sx, const float *sy,
+                              const float *sz, size_t n, float max_distance, uint32_t *tgt_idx,
+                              float *dist, size_t *n_corr);
+int pcrs_find_correspondences_dev(pcrs_index *target, const float *dsx, const float *dsy,
+                                  const float *dsz, size_t n, float max_distance,
+                                  uint32_t *dtgt_idx, float *ddist, size_t *n_corr);
+
+/* ICP state: target index (+ target normals for point-to-plane) and the working
+ * copy `current` of the source, all device-resident across iterations
+ * (the loop of icp.rs:125-206 / icp_plane.rs:20-97).
+ * tnx/tny/tnz may be NULL (point-to-point only); n_normals is the length of
+ * the normals columns and must equal m for point-to-plane. */
+int pcrs_icp_create(pcrs_ctx *ctx, const float *sx, const float *sy, const float *sz, size_t n,
+                    const float *tx, const float *ty, const float *tz, size_t m, const float *tnx,
+                    const float *tny, const float *tnz, size_t n_normals, pcrs_icp **out);
+int pcrs_icp_create_dev(pcrs_ctx *ctx, const float *dsx, const float *dsy, const float *dsz,
+                        size_t n, const float *dtx, const float *dty, const float *dtz, size_t m,
+                        const float *dtnx, const float *dtny, const float *dtnz, size_t n_normals,
+                        pcrs_icp **out);
+void pcrs_icp_destroy(pcrs_icp *icp);
+/* current <- source (icp.rs:145) */
+int pcrs_icp_reset(pcrs_icp *icp);
+
+/* One correspondence pass over `current` fused with the consumer reduction
+ * (correspondence.rs:23-36 + icp.rs:221-244,277-281 / icp_plane.rs:148-180).
+ * sums[PCRS_ICP_NSUMS], all f64, host memory:
+ *   [0]      correspondence count
+ *   [1]      sum of dist*dist (each product rounded to f32 first, icp.rs:279)
+ *   mode POINT_TO_PLANE: [2..22] upper triangle of A^T A row by row
+ *                        (00 01 02 03 04 05 11 12 ... 55), [23..28] A^T b
+ *   mode POINT_TO_POINT: [2..4] sum s, [5..7] sum t, [8..16] sum s t^T row-major
+ * Unused entries are zero.  Sums are additive across shards of the source, so
+ * a multi-GPU job all-reduces this array between accumulate and update. */
+int pcrs_icp_accumulate(pcrs_icp *icp, int mode, float max_distance, double *sums);
+
+/* The incremental transform of one iteration from (all-reduced) sums:
+ * solve_point_to_plane's Tikhonov + Cholesky/LU + Rodrigues
+ * (icp_plane.rs:182-235) or compute_rigid_transform_svd (icp.rs:246-269). */
+int pcrs_icp_solve(int mode, const double *sums, float rotation[9], float translation[3]);
+
+/* current <- R*current + t in place (icp.rs:186, icp_plane.rs:78) */
+int pcrs_icp_apply(pcrs_icp *icp, const float rotation[9], const float translation[3]);
+
+/* Downloads the working copy of the source. */
+int pcrs_icp_get_current(pcrs_icp *icp, float *x, float *y, float *z);
+
+/* icp_point_to_point / icp_point_to_plane — icp.rs:125-206, icp_plane.rs:20-97.
+ * Starts from current = source.  Returns PCRS_ERR_NORMALS_MISMATCH for
+ * point-to-plane when the normals length differs from the target length. */
+int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float tolerance,
+                 float max_correspondence_distance, pcrs_icp_result *out);
+
+/* Whole registration on host buffers (create + run + destroy). */
+int pcrs_icp_register(pcrs_ctx *ctx, int mode, const float *sx, const float *sy, const float *sz, size_t n,
+             const float *tx, const float *ty, const float *tz, size_t m, const float *tnx,
+             const float *tny, const float *tnz, size_t n_normals, uint32_t max_iterations,
+             float tolerance, float max_correspondence_distance, pcrs_icp_result *out);
+
+/* ------------------------------------------------------------ diagnostics */
+
+/* Benchmark instrumentation (no counterpart in the reference): when enabled,
+ * every launch of the neighbour-search kernel is bracketed by HIP events on
+ * the context's stream.  pcrs_ctx_timing_read synchronises, returns the summed
+ * kernel time and the number of bracketed launches since the last read, and
+ * resets both. */
+int pcrs_ctx_timing(pcrs_ctx *ctx, int enable);
+int pcrs_ctx_timing_read(pcrs_ctx *ctx, double *total_ms, uint64_t *launches);
+
+/* Counters of the last query call on this index: [0] queries answered by the
+ * grid tile kernel, [1] by the ring-search fallback, [2] by brute force. */
+int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCRS_HIP_H */

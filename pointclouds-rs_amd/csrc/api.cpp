@@ -1,0 +1,1012 @@
+// C-ABI of libpcrs_hip.so: argument checking, device-memory plumbing and the host-side control
+// flow of the reference functions (edge cases, ICP outer loop).  All numeric work on point data is
+// done by the HIP kernels; there is no CPU fallback — without a GPU every entry point fails.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "pcrs_internal.h"
+
+// ------------------------------------------------------------------------------------ helpers
+
+int pcrs_set_err(pcrs_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int pcrs_ctx_scratch(pcrs_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) {
+            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            PCRS_HIP_CHECK(ctx, hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        size_t want = bytes + bytes / 4 + 4096;
+        PCRS_HIP_CHECK(ctx, hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return PCRS_OK;
+}
+
+int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->pinned_bytes) {
+        if (ctx->pinned) {
+            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            PCRS_HIP_CHECK(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+        }
+        size_t want = bytes + bytes / 4 + 4096;
+        PCRS_HIP_CHECK(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return PCRS_OK;
+}
+
+void pcrs_timing_begin(pcrs_ctx *ctx) {
+    if (!ctx->timing) return;
+    if (ctx->ev_used == ctx->ev_start.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            ctx->timing = false;
+            return;
+        }
+        ctx->ev_start.push_back(a);
+        ctx->ev_stop.push_back(b);
+    }
+    (void)hipEventRecord(ctx->ev_start[ctx->ev_used], ctx->stream);
+}
+
+void pcrs_timing_end(pcrs_ctx *ctx) {
+    if (!ctx->timing || ctx->ev_used >= ctx->ev_stop.size()) return;
+    (void)hipEventRecord(ctx->ev_stop[ctx->ev_used], ctx->stream);
+    ctx->ev_used++;
+}
+
+namespace {
+
+#define PCRS_TRY(expr)                \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != PCRS_OK) return _rc; \
+    } while (0)
+
+int bind_device(pcrs_ctx *ctx) {
+    if (!ctx) return PCRS_ERR_INVALID_ARG;
+    PCRS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return PCRS_OK;
+}
+
+int upload(pcrs_ctx *ctx, DevBuf &dst, const float *src, size_t n) {
+    PCRS_HIP_CHECK(ctx, dst.alloc(n * sizeof(float)));
+    if (n) PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dst.p, src, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return PCRS_OK;
+}
+
+int download(pcrs_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes) PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PCRS_OK;
+}
+
+int run_query(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed) {
+    ix->stats[0] = ix->stats[1] = ix->stats[2] = 0;
+    if (ix->algo == PCRS_ALGO_GRID) return pcrs_launch_knn_grid(ix, q, out, kneed);
+    ix->stats[2] = q.nq;
+    return pcrs_launch_knn_bf(ix->ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, nullptr, nullptr,
+                              0);
+}
+
+// Below this size the whole cloud fits a handful of LDS tiles and the grid build is not worth it.
+constexpr size_t kGridMinPoints = 4096;
+
+int finish_index(pcrs_index *ix, uint32_t k_hint, int algo) {
+    if (algo != PCRS_ALGO_AUTO && algo != PCRS_ALGO_BRUTE && algo != PCRS_ALGO_GRID)
+        return pcrs_set_err(ix->ctx, PCRS_ERR_INVALID_ARG, "unknown algo %d", algo);
+    if (ix->m >= 0xFFFFFFFFull)
+        return pcrs_set_err(ix->ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    ix->algo = PCRS_ALGO_BRUTE;
+    const bool want_grid =
+        algo == PCRS_ALGO_GRID || (algo == PCRS_ALGO_AUTO && ix->m >= kGridMinPoints);
+    if (want_grid && ix->m > 0) {
+        PCRS_TRY(pcrs_grid_build(ix, k_hint));  // leaves algo == BRUTE when a grid cannot help
+    }
+    return PCRS_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ context
+
+extern "C" {
+
+const char *pcrs_version(void) { return "pcrs-hip 0.1 (gfx950)"; }
+
+int pcrs_ctx_create(int device, pcrs_ctx **out) {
+    if (!out) return PCRS_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PCRS_ERR_HIP;
+    if (device < 0 || device >= count) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = new (std::nothrow) pcrs_ctx();
+    if (!ctx) return PCRS_ERR_OOM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return PCRS_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+        cus > 0)
+        ctx->num_cus = cus;
+    *out = ctx;
+    return PCRS_OK;
+}
+
+int pcrs_ctx_set_stream(pcrs_ctx *ctx, void *hip_stream) {
+    PCRS_TRY(bind_device(ctx));
+    if (ctx->own_stream && ctx->stream) {
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        PCRS_HIP_CHECK(ctx, hipStreamDestroy(ctx->stream));
+    }
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return PCRS_OK;
+}
+
+void pcrs_ctx_destroy(pcrs_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->ev_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_stop) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pcrs_ctx_timing(pcrs_ctx *ctx, int enable) {
+    PCRS_TRY(bind_device(ctx));
+    ctx->timing = enable != 0;
+    ctx->ev_used = 0;
+    return PCRS_OK;
+}
+
+int pcrs_ctx_timing_read(pcrs_ctx *ctx, double *total_ms, uint64_t *launches) {
+    PCRS_TRY(bind_device(ctx));
+    if (!total_ms || !launches) return PCRS_ERR_INVALID_ARG;
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0.0f;
+        PCRS_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = ctx->ev_used;
+    ctx->ev_used = 0;
+    return PCRS_OK;
+}
+
+const char *pcrs_last_error(const pcrs_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pcrs_ctx_synchronize(pcrs_ctx *ctx) {
+    PCRS_TRY(bind_device(ctx));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
+// -------------------------------------------------------------------------------------- index
+
+int pcrs_index_build_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                         size_t m, uint32_t k_hint, int algo, pcrs_index **out) {
+    if (!out) return PCRS_ERR_INVALID_ARG;
+    *out = nullptr;
+    PCRS_TRY(bind_device(ctx));
+    if (m && (!dx || !dy || !dz))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    pcrs_index *ix = new (std::nothrow) pcrs_index();
+    if (!ix) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    ix->ctx = ctx;
+    ix->x = dx;
+    ix->y = dy;
+    ix->z = dz;
+    ix->m = m;
+    int rc = finish_index(ix, k_hint, algo);
+    if (rc != PCRS_OK) {
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return PCRS_OK;
+}
+
+int pcrs_index_build(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t m,
+                     uint32_t k_hint, int algo, pcrs_index **out) {
+    if (!out) return PCRS_ERR_INVALID_ARG;
+    *out = nullptr;
+    PCRS_TRY(bind_device(ctx));
+    if (m && (!x || !y || !z)) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    pcrs_index *ix = new (std::nothrow) pcrs_index();
+    if (!ix) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    ix->ctx = ctx;
+    int rc = upload(ctx, ix->own_x, x, m);
+    if (rc == PCRS_OK) rc = upload(ctx, ix->own_y, y, m);
+    if (rc == PCRS_OK) rc = upload(ctx, ix->own_z, z, m);
+    if (rc == PCRS_OK) {
+        ix->x = ix->own_x.as<float>();
+        ix->y = ix->own_y.as<float>();
+        ix->z = ix->own_z.as<float>();
+        ix->m = m;
+        rc = finish_index(ix, k_hint, algo);
+    }
+    if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed after index upload");
+    if (rc != PCRS_OK) {
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return PCRS_OK;
+}
+
+void pcrs_index_destroy(pcrs_index *index) {
+    if (!index) return;
+    if (index->ctx) {
+        (void)hipSetDevice(index->ctx->device);
+        (void)hipStreamSynchronize(index->ctx->stream);
+    }
+    delete index;
+}
+
+size_t pcrs_index_len(const pcrs_index *index) { return index ? index->m : 0; }
+
+int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]) {
+    if (!index || !stats) return PCRS_ERR_INVALID_ARG;
+    for (int i = 0; i < 3; ++i) stats[i] = index->stats[i];
+    return PCRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------- knn
+
+int pcrs_knn_batch_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
+                       size_t n, uint32_t k, uint32_t *didx, float *ddist, uint32_t *dcount) {
+    if (!index) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (n == 0) return PCRS_OK;
+    if (!dqx || !dqy || !dqz) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null query pointer");
+    if (k == 0) {  // kdtree.rs:65
+        if (dcount) PCRS_HIP_CHECK(ctx, hipMemsetAsync(dcount, 0, n * sizeof(uint32_t), ctx->stream));
+        return PCRS_OK;
+    }
+    if (!didx && !ddist && !dcount) return PCRS_OK;
+    KnnQuery q;
+    q.qx = dqx;
+    q.qy = dqy;
+    q.qz = dqz;
+    q.nq = n;
+    KnnOut o;
+    o.idx = didx;
+    o.dist = ddist;
+    o.count = dcount;
+    o.k = k;
+    return run_query(index, q, o, k);
+}
+
+int pcrs_knn_batch(pcrs_index *index, const float *qx, const float *qy, const float *qz, size_t n,
+                   uint32_t k, uint32_t *idx, float *dist, uint32_t *count) {
+    if (!index) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (n == 0) return PCRS_OK;
+    if (!qx || !qy || !qz) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null query pointer");
+    DevBuf dqx, dqy, dqz, didx, ddist, dcount;
+    PCRS_TRY(upload(ctx, dqx, qx, n));
+    PCRS_TRY(upload(ctx, dqy, qy, n));
+    PCRS_TRY(upload(ctx, dqz, qz, n));
+    const size_t nk = n * (size_t)k;
+    if (idx) PCRS_HIP_CHECK(ctx, didx.alloc(nk * sizeof(uint32_t)));
+    if (dist) PCRS_HIP_CHECK(ctx, ddist.alloc(nk * sizeof(float)));
+    if (count) PCRS_HIP_CHECK(ctx, dcount.alloc(n * sizeof(uint32_t)));
+    PCRS_TRY(pcrs_knn_batch_dev(index, dqx.as<float>(), dqy.as<float>(), dqz.as<float>(), n, k,
+                                idx ? didx.as<uint32_t>() : nullptr,
+                                dist ? ddist.as<float>() : nullptr,
+                                count ? dcount.as<uint32_t>() : nullptr));
+    if (idx) PCRS_TRY(download(ctx, idx, didx.p, nk * sizeof(uint32_t)));
+    if (dist) PCRS_TRY(download(ctx, dist, ddist.p, nk * sizeof(float)));
+    if (count) PCRS_TRY(download(ctx, count, dcount.p, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
+int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
+                          size_t n, float radius, uint32_t *dcount) {
+    if (!index || !dcount) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    return pcrs_launch_radius_count(ctx, index->x, index->y, index->z, index->m, dqx, dqy, dqz, n,
+                                    radius, dcount);
+}
+
+int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const float *qz,
+                      size_t n, float radius, uint32_t *count) {
+    if (!index || !count) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (n == 0) return PCRS_OK;
+    DevBuf dqx, dqy, dqz, dcount;
+    PCRS_TRY(upload(ctx, dqx, qx, n));
+    PCRS_TRY(upload(ctx, dqy, qy, n));
+    PCRS_TRY(upload(ctx, dqz, qz, n));
+    PCRS_HIP_CHECK(ctx, dcount.alloc(n * sizeof(uint32_t)));
+    PCRS_TRY(pcrs_radius_count_dev(index, dqx.as<float>(), dqy.as<float>(), dqz.as<float>(), n,
+                                   radius, dcount.as<uint32_t>()));
+    PCRS_TRY(download(ctx, count, dcount.p, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
+// -------------------------------------------------------------------------- SOR and normals
+
+static int check_range(pcrs_index *index, size_t q_begin, size_t q_count) {
+    if (q_begin > index->m || q_count > index->m - q_begin)
+        return pcrs_set_err(index->ctx, PCRS_ERR_INVALID_ARG,
+                            "query range [%zu, +%zu) exceeds the indexed cloud (%zu points)",
+                            q_begin, q_count, index->m);
+    return PCRS_OK;
+}
+
+int pcrs_sor_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k_sor,
+                         uint32_t k_normals, const float viewpoint[3], float *dmean, float *dnx,
+                         float *dny, float *dnz) {
+    if (!index) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    PCRS_TRY(check_range(index, q_begin, q_count));
+    const bool want_n = dnx || dny || dnz;
+    if (want_n && !(dnx && dny && dnz))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "normals need all three output columns");
+    if (dmean && k_sor == 0) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_sor must be >= 1");
+    if (want_n && (k_normals == 0 || !viewpoint))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_normals must be >= 1 with a viewpoint");
+    if (q_count == 0 || (!dmean && !want_n)) return PCRS_OK;
+    KnnQuery q;
+    q.qx = index->x + q_begin;
+    q.qy = index->y + q_begin;
+    q.qz = index->z + q_begin;
+    q.nq = q_count;
+    q.out_offset = q_begin;
+    q.self = true;
+    KnnOut o;
+    uint32_t kneed = 1;
+    if (dmean) {
+        o.mean = dmean;
+        o.k_sor = k_sor;
+        if (k_sor == 0xFFFFFFFFu) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_sor too large");
+        kneed = k_sor + 1;
+    }
+    if (want_n) {
+        o.nx = dnx;
+        o.ny = dny;
+        o.nz = dnz;
+        o.k_nrm = k_normals;
+        o.vp[0] = viewpoint[0];
+        o.vp[1] = viewpoint[1];
+        o.vp[2] = viewpoint[2];
+        if (k_normals > kneed) kneed = k_normals;
+    }
+    return run_query(index, q, o, kneed);
+}
+
+int pcrs_sor_mean_dist_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
+                           float *dmean) {
+    if (!dmean) return PCRS_ERR_INVALID_ARG;
+    return pcrs_sor_normals_dev(index, q_begin, q_count, k, 0, nullptr, dmean, nullptr, nullptr,
+                                nullptr);
+}
+
+int pcrs_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
+                     const float viewpoint[3], float *dnx, float *dny, float *dnz) {
+    if (!dnx || !dny || !dnz) return PCRS_ERR_INVALID_ARG;
+    return pcrs_sor_normals_dev(index, q_begin, q_count, 0, k, viewpoint, nullptr, dnx, dny, dnz);
+}
+
+int pcrs_sor_threshold_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul, float *thr,
+                           int *has_finite) {
+    PCRS_TRY(bind_device(ctx));
+    if (!thr || !has_finite) return PCRS_ERR_INVALID_ARG;
+    return pcrs_sor_threshold_impl(ctx, dmean, n, std_mul, thr, has_finite);
+}
+
+int pcrs_sor_mask_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float thr, uint8_t *dkeep,
+                      size_t *n_keep) {
+    PCRS_TRY(bind_device(ctx));
+    if (n_keep) *n_keep = 0;
+    if (n == 0) return PCRS_OK;
+    if (!dmean || !dkeep) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    unsigned long long *dcount = nullptr;
+    unsigned long long *hcount = nullptr;
+    if (n_keep) {
+        void *p = nullptr;
+        PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &p));
+        hcount = reinterpret_cast<unsigned long long *>(p);
+        void *s = nullptr;
+        PCRS_TRY(pcrs_ctx_scratch(ctx, 64, &s));
+        dcount = reinterpret_cast<unsigned long long *>(s);
+    }
+    PCRS_TRY(pcrs_launch_mask(ctx, dmean, n, thr, dkeep, dcount));
+    if (n_keep) {
+        PCRS_TRY(download(ctx, hcount, dcount, sizeof(unsigned long long)));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        *n_keep = (size_t)*hcount;
+    }
+    return PCRS_OK;
+}
+
+// statistical_outlier.rs:43-62 on host memory: strictly left-to-right f32 sums.
+static bool host_threshold(const float *mean, size_t n, float std_mul, float *thr) {
+    size_t nf = 0;
+    float s = 0.0f;
+    for (size_t i = 0; i < n; ++i)
+        if (std::isfinite(mean[i])) {
+            s += mean[i];
+            ++nf;
+        }
+    if (nf == 0) return false;
+    const float nn = (float)nf;
+    const float mu = s / nn;
+    float v = 0.0f;
+    for (size_t i = 0; i < n; ++i)
+        if (std::isfinite(mean[i])) {
+            const float d = mean[i] - mu;
+            v += d * d;
+        }
+    v = v / nn;
+    const float sd = std::sqrt(v);
+    *thr = mu + std_mul * sd;
+    return true;
+}
+
+int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                     uint32_t k_sor, float std_mul, uint32_t k_normals, const float viewpoint[3],
+                     uint8_t *keep, size_t *n_keep, float *thr_out, float *nx, float *ny,
+                     float *nz) {
+    PCRS_TRY(bind_device(ctx));
+    const bool want_sor = keep != nullptr;
+    const bool want_n = nx || ny || nz;
+    if (n_keep) *n_keep = 0;
+    if (thr_out) *thr_out = std::numeric_limits<float>::quiet_NaN();
+    if (want_n && !(nx && ny && nz && viewpoint))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "normals need three columns and a viewpoint");
+    if (n == 0) return PCRS_OK;
+    if (!x || !y || !z) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    // statistical_outlier.rs:5-12, estimate.rs:25-31
+    bool run_sor = want_sor, run_n = want_n && k_normals > 0;
+    if (want_sor) {
+        if (k_sor == 0) {
+            std::memset(keep, 0, n);
+            run_sor = false;
+        } else if (n == 1) {
+            keep[0] = 1;
+            if (n_keep) *n_keep = 1;
+            run_sor = false;
+        }
+    }
+    if (!run_sor && !run_n) return PCRS_OK;
+
+    pcrs_index *ix = nullptr;
+    const uint32_t hint = run_sor ? k_sor + 1 : k_normals;
+    PCRS_TRY(pcrs_index_build(ctx, x, y, z, n, hint, PCRS_ALGO_AUTO, &ix));
+    DevBuf dmean, dnx, dny, dnz;
+    int rc = PCRS_OK;
+    auto fail = [&](int code) {
+        pcrs_index_destroy(ix);
+        return code;
+    };
+    if (run_sor && dmean.alloc(n * sizeof(float)) != hipSuccess)
+        return fail(pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed"));
+    if (run_n && (dnx.alloc(n * sizeof(float)) != hipSuccess ||
+                  dny.alloc(n * sizeof(float)) != hipSuccess ||
+                  dnz.alloc(n * sizeof(float)) != hipSuccess))
+        return fail(pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed"));
+    rc = pcrs_sor_normals_dev(ix, 0, n, run_sor ? k_sor : 0, run_n ? k_normals : 0, viewpoint,
+                              run_sor ? dmean.as<float>() : nullptr,
+                              run_n ? dnx.as<float>() : nullptr, run_n ? dny.as<float>() : nullptr,
+                              run_n ? dnz.as<float>() : nullptr);
+    if (rc != PCRS_OK) return fail(rc);
+    std::vector<float> hmean;
+    if (run_sor) {
+        hmean.resize(n);
+        rc = download(ctx, hmean.data(), dmean.p, n * sizeof(float));
+        if (rc != PCRS_OK) return fail(rc);
+    }
+    if (run_n) {
+        rc = download(ctx, nx, dnx.p, n * sizeof(float));
+        if (rc == PCRS_OK) rc = download(ctx, ny, dny.p, n * sizeof(float));
+        if (rc == PCRS_OK) rc = download(ctx, nz, dnz.p, n * sizeof(float));
+        if (rc != PCRS_OK) return fail(rc);
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed"));
+    pcrs_index_destroy(ix);
+    if (run_sor) {
+        float thr;
+        size_t kept = 0;
+        if (!host_threshold(hmean.data(), n, std_mul, &thr)) {  // :49-51
+            std::memset(keep, 0, n);
+        } else {
+            if (thr_out) *thr_out = thr;
+            for (size_t i = 0; i < n; ++i) {  // :64-66
+                keep[i] = hmean[i] <= thr ? 1 : 0;
+                kept += keep[i];
+            }
+        }
+        if (n_keep) *n_keep = kept;
+    }
+    return PCRS_OK;
+}
+
+int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n, uint32_t k,
+             float std_mul, uint8_t *keep, size_t *n_keep, float *thr_out, float *mean_out) {
+    if (!keep) return PCRS_ERR_INVALID_ARG;
+    if (!mean_out)
+        return pcrs_sor_normals(ctx, x, y, z, n, k, std_mul, 0, nullptr, keep, n_keep, thr_out,
+                                nullptr, nullptr, nullptr);
+    // same flow, keeping the per-point means for the caller
+    PCRS_TRY(bind_device(ctx));
+    if (n_keep) *n_keep = 0;
+    if (thr_out) *thr_out = std::numeric_limits<float>::quiet_NaN();
+    if (n == 0) return PCRS_OK;
+    if (k == 0) {
+        std::memset(keep, 0, n);
+        return PCRS_OK;
+    }
+    if (n == 1) {
+        keep[0] = 1;
+        if (n_keep) *n_keep = 1;
+        return PCRS_OK;
+    }
+    pcrs_index *ix = nullptr;
+    PCRS_TRY(pcrs_index_build(ctx, x, y, z, n, k + 1, PCRS_ALGO_AUTO, &ix));
+    DevBuf dmean;
+    int rc = dmean.alloc(n * sizeof(float)) == hipSuccess
+                 ? PCRS_OK
+                 : pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed");
+    if (rc == PCRS_OK) rc = pcrs_sor_mean_dist_dev(ix, 0, n, k, dmean.as<float>());
+    if (rc == PCRS_OK) rc = download(ctx, mean_out, dmean.p, n * sizeof(float));
+    if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed");
+    pcrs_index_destroy(ix);
+    if (rc != PCRS_OK) return rc;
+    float thr;
+    size_t kept = 0;
+    if (!host_threshold(mean_out, n, std_mul, &thr)) {
+        std::memset(keep, 0, n);
+    } else {
+        if (thr_out) *thr_out = thr;
+        for (size_t i = 0; i < n; ++i) {
+            keep[i] = mean_out[i] <= thr ? 1 : 0;
+            kept += keep[i];
+        }
+    }
+    if (n_keep) *n_keep = kept;
+    return PCRS_OK;
+}
+
+int pcrs_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                 uint32_t k, const float viewpoint[3], float *nx, float *ny, float *nz) {
+    if (!nx || !ny || !nz || !viewpoint) return PCRS_ERR_INVALID_ARG;
+    return pcrs_sor_normals(ctx, x, y, z, n, 0, 0.0f, k, viewpoint, nullptr, nullptr, nullptr, nx,
+                            ny, nz);
+}
+
+// ------------------------------------------------------------------------------ registration
+
+void pcrs_compose(const float ra[9], const float ta[3], const float rb[9], const float tb[3],
+                  float rout[9], float tout[3]) {
+    pcrs_host_compose(ra, ta, rb, tb, rout, tout);
+}
+
+int pcrs_apply_transform_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                             size_t n, const float rotation[9], const float translation[3],
+                             float *dox, float *doy, float *doz) {
+    PCRS_TRY(bind_device(ctx));
+    if (!rotation || !translation) return PCRS_ERR_INVALID_ARG;
+    if (n == 0) return PCRS_OK;
+    if (!dx || !dy || !dz || !dox || !doy || !doz)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    return pcrs_launch_transform(ctx, dx, dy, dz, n, rotation, translation, dox, doy, doz);
+}
+
+int pcrs_apply_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                         const float rotation[9], const float translation[3], float *ox,
+                         float *oy, float *oz) {
+    PCRS_TRY(bind_device(ctx));
+    if (n == 0) return PCRS_OK;
+    if (!x || !y || !z || !ox || !oy || !oz || !rotation || !translation)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    DevBuf dx, dy, dz;
+    PCRS_TRY(upload(ctx, dx, x, n));
+    PCRS_TRY(upload(ctx, dy, y, n));
+    PCRS_TRY(upload(ctx, dz, z, n));
+    PCRS_TRY(pcrs_launch_transform(ctx, dx.as<float>(), dy.as<float>(), dz.as<float>(), n,
+                                   rotation, translation, dx.as<float>(), dy.as<float>(),
+                                   dz.as<float>()));
+    PCRS_TRY(download(ctx, ox, dx.p, n * sizeof(float)));
+    PCRS_TRY(download(ctx, oy, dy.p, n * sizeof(float)));
+    PCRS_TRY(download(ctx, oz, dz.p, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
+}  // extern "C"
+
+struct pcrs_icp {
+    pcrs_ctx *ctx = nullptr;
+    pcrs_index *target = nullptr;  // owned
+    const float *tnx = nullptr, *tny = nullptr, *tnz = nullptr;
+    size_t n_normals = 0;
+    const float *sx = nullptr, *sy = nullptr, *sz = nullptr;
+    size_t n = 0, m = 0;
+    DevBuf own_s[3], own_t[3], own_n[3];
+    DevBuf cur[3];
+    DevBuf nn_idx, nn_d2, sums;
+};
+
+namespace {
+
+// shared by find_correspondences and the ICP accumulate step
+int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const float *cx,
+                          const float *cy, const float *cz, size_t n, const float *tnx,
+                          const float *tny, const float *tnz, float max_d, uint32_t *nn_idx,
+                          float *nn_d2, double *dsums, uint32_t *tgt_out, float *dist_out) {
+    KnnQuery q;
+    q.qx = cx;
+    q.qy = cy;
+    q.qz = cz;
+    q.nq = n;
+    KnnOut o;
+    o.nn_idx = nn_idx;
+    o.nn_d2 = nn_d2;
+    PCRS_TRY(run_query(target, q, o, 1));
+    return pcrs_launch_icp_reduce(ctx, mode, cx, cy, cz, n, target->x, target->y, target->z, tnx,
+                                  tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums);
+}
+
+int icp_alloc_work(pcrs_icp *icp) {
+    pcrs_ctx *ctx = icp->ctx;
+    const size_t n = icp->n;
+    for (int a = 0; a < 3; ++a) PCRS_HIP_CHECK(ctx, icp->cur[a].alloc(n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, icp->nn_idx.alloc(n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, icp->nn_d2.alloc(n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, icp->sums.alloc(PCRS_ICP_NSUMS * sizeof(double)));
+    return PCRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcrs_find_correspondences_dev(pcrs_index *target, const float *dsx, const float *dsy,
+                                  const float *dsz, size_t n, float max_distance,
+                                  uint32_t *dtgt_idx, float *ddist, size_t *n_corr) {
+    if (!target) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = target->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (n_corr) *n_corr = 0;
+    if (n == 0) return PCRS_OK;
+    if (!dsx || !dsy || !dsz) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    DevBuf nn_idx, nn_d2, sums;
+    PCRS_HIP_CHECK(ctx, nn_idx.alloc(n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, nn_d2.alloc(n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, sums.alloc(PCRS_ICP_NSUMS * sizeof(double)));
+    PCRS_TRY(correspond_and_reduce(ctx, target, PCRS_ICP_POINT_TO_POINT, dsx, dsy, dsz, n, nullptr,
+                                   nullptr, nullptr, max_distance, nn_idx.as<uint32_t>(),
+                                   nn_d2.as<float>(), sums.as<double>(), dtgt_idx, ddist));
+    double h[2] = {0, 0};
+    PCRS_TRY(download(ctx, h, sums.p, sizeof(h)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_corr) *n_corr = (size_t)h[0];
+    return PCRS_OK;
+}
+
+int pcrs_find_correspondences(pcrs_index *target, const float *sx, const float *sy,
+                              const float *sz, size_t n, float max_distance, uint32_t *tgt_idx,
+                              float *dist, size_t *n_corr) {
+    if (!target) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = target->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (n_corr) *n_corr = 0;
+    if (n == 0) return PCRS_OK;
+    if (!sx || !sy || !sz) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    DevBuf dx, dy, dz, dti, dd;
+    PCRS_TRY(upload(ctx, dx, sx, n));
+    PCRS_TRY(upload(ctx, dy, sy, n));
+    PCRS_TRY(upload(ctx, dz, sz, n));
+    PCRS_HIP_CHECK(ctx, dti.alloc(n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, dd.alloc(n * sizeof(float)));
+    PCRS_TRY(pcrs_find_correspondences_dev(target, dx.as<float>(), dy.as<float>(), dz.as<float>(),
+                                           n, max_distance, dti.as<uint32_t>(), dd.as<float>(),
+                                           n_corr));
+    if (tgt_idx) PCRS_TRY(download(ctx, tgt_idx, dti.p, n * sizeof(uint32_t)));
+    if (dist) PCRS_TRY(download(ctx, dist, dd.p, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
+int pcrs_icp_create_dev(pcrs_ctx *ctx, const float *dsx, const float *dsy, const float *dsz,
+                        size_t n, const float *dtx, const float *dty, const float *dtz, size_t m,
+                        const float *dtnx, const float *dtny, const float *dtnz, size_t n_normals,
+                        pcrs_icp **out) {
+    if (!out) return PCRS_ERR_INVALID_ARG;
+    *out = nullptr;
+    PCRS_TRY(bind_device(ctx));
+    if ((n && (!dsx || !dsy || !dsz)) || (m && (!dtx || !dty || !dtz)))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    const bool have_n = dtnx && dtny && dtnz;
+    pcrs_icp *icp = new (std::nothrow) pcrs_icp();
+    if (!icp) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    icp->ctx = ctx;
+    icp->sx = dsx;
+    icp->sy = dsy;
+    icp->sz = dsz;
+    icp->n = n;
+    icp->m = m;
+    icp->tnx = have_n ? dtnx : nullptr;
+    icp->tny = have_n ? dtny : nullptr;
+    icp->tnz = have_n ? dtnz : nullptr;
+    icp->n_normals = have_n ? n_normals : 0;
+    int rc = pcrs_index_build_dev(ctx, dtx, dty, dtz, m, 1, PCRS_ALGO_AUTO, &icp->target);
+    if (rc == PCRS_OK) rc = icp_alloc_work(icp);
+    if (rc == PCRS_OK) rc = pcrs_icp_reset(icp);
+    if (rc != PCRS_OK) {
+        pcrs_icp_destroy(icp);
+        return rc;
+    }
+    *out = icp;
+    return PCRS_OK;
+}
+
+int pcrs_icp_create(pcrs_ctx *ctx, const float *sx, const float *sy, const float *sz, size_t n,
+                    const float *tx, const float *ty, const float *tz, size_t m, const float *tnx,
+                    const float *tny, const float *tnz, size_t n_normals, pcrs_icp **out) {
+    if (!out) return PCRS_ERR_INVALID_ARG;
+    *out = nullptr;
+    PCRS_TRY(bind_device(ctx));
+    if ((n && (!sx || !sy || !sz)) || (m && (!tx || !ty || !tz)))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    const bool have_n = tnx && tny && tnz;
+    pcrs_icp *icp = new (std::nothrow) pcrs_icp();
+    if (!icp) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    icp->ctx = ctx;
+    icp->n = n;
+    icp->m = m;
+    const float *s[3] = {sx, sy, sz}, *t[3] = {tx, ty, tz}, *nn[3] = {tnx, tny, tnz};
+    int rc = PCRS_OK;
+    for (int a = 0; a < 3 && rc == PCRS_OK; ++a) rc = upload(ctx, icp->own_s[a], s[a], n);
+    for (int a = 0; a < 3 && rc == PCRS_OK; ++a) rc = upload(ctx, icp->own_t[a], t[a], m);
+    if (have_n)
+        for (int a = 0; a < 3 && rc == PCRS_OK; ++a) rc = upload(ctx, icp->own_n[a], nn[a], n_normals);
+    if (rc == PCRS_OK) {
+        icp->sx = icp->own_s[0].as<float>();
+        icp->sy = icp->own_s[1].as<float>();
+        icp->sz = icp->own_s[2].as<float>();
+        if (have_n) {
+            icp->tnx = icp->own_n[0].as<float>();
+            icp->tny = icp->own_n[1].as<float>();
+            icp->tnz = icp->own_n[2].as<float>();
+            icp->n_normals = n_normals;
+        }
+        rc = pcrs_index_build_dev(ctx, icp->own_t[0].as<float>(), icp->own_t[1].as<float>(),
+                                  icp->own_t[2].as<float>(), m, 1, PCRS_ALGO_AUTO, &icp->target);
+    }
+    if (rc == PCRS_OK) rc = icp_alloc_work(icp);
+    if (rc == PCRS_OK) rc = pcrs_icp_reset(icp);
+    if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed");
+    if (rc != PCRS_OK) {
+        pcrs_icp_destroy(icp);
+        return rc;
+    }
+    *out = icp;
+    return PCRS_OK;
+}
+
+void pcrs_icp_destroy(pcrs_icp *icp) {
+    if (!icp) return;
+    if (icp->ctx) {
+        (void)hipSetDevice(icp->ctx->device);
+        (void)hipStreamSynchronize(icp->ctx->stream);
+    }
+    pcrs_index_destroy(icp->target);
+    delete icp;
+}
+
+int pcrs_icp_reset(pcrs_icp *icp) {
+    if (!icp) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    // icp.rs:145: apply_transform(source, identity) — evaluated, not copied, so that the f32
+    // result matches the reference for signed zeros and non-finite inputs.
+    const float rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    return pcrs_launch_transform(ctx, icp->sx, icp->sy, icp->sz, icp->n, rot, t,
+                                 icp->cur[0].as<float>(), icp->cur[1].as<float>(),
+                                 icp->cur[2].as<float>());
+}
+
+int pcrs_icp_accumulate(pcrs_icp *icp, int mode, float max_distance, double *sums) {
+    if (!icp || !sums) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (mode != PCRS_ICP_POINT_TO_POINT && mode != PCRS_ICP_POINT_TO_PLANE)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "unknown ICP mode %d", mode);
+    if (mode == PCRS_ICP_POINT_TO_PLANE && (!icp->tnx || icp->n_normals != icp->m))
+        return pcrs_set_err(ctx, PCRS_ERR_NORMALS_MISMATCH,
+                            "target_normals length (%zu) does not match target cloud length (%zu)",
+                            icp->n_normals, icp->m);
+    PCRS_TRY(correspond_and_reduce(ctx, icp->target, mode, icp->cur[0].as<float>(),
+                                   icp->cur[1].as<float>(), icp->cur[2].as<float>(), icp->n,
+                                   icp->tnx, icp->tny, icp->tnz, max_distance,
+                                   icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
+                                   icp->sums.as<double>(), nullptr, nullptr));
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, PCRS_ICP_NSUMS * sizeof(double), &pin));
+    PCRS_TRY(download(ctx, pin, icp->sums.p, PCRS_ICP_NSUMS * sizeof(double)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(sums, pin, PCRS_ICP_NSUMS * sizeof(double));
+    return PCRS_OK;
+}
+
+int pcrs_icp_solve(int mode, const double *sums, float rotation[9], float translation[3]) {
+    if (!sums || !rotation || !translation) return PCRS_ERR_INVALID_ARG;
+    if (mode == PCRS_ICP_POINT_TO_PLANE)
+        pcrs_host_solve_plane(sums, rotation, translation);
+    else if (mode == PCRS_ICP_POINT_TO_POINT)
+        pcrs_host_solve_point(sums, rotation, translation);
+    else
+        return PCRS_ERR_INVALID_ARG;
+    return PCRS_OK;
+}
+
+int pcrs_icp_apply(pcrs_icp *icp, const float rotation[9], const float translation[3]) {
+    if (!icp || !rotation || !translation) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    float *cx = icp->cur[0].as<float>(), *cy = icp->cur[1].as<float>(), *cz = icp->cur[2].as<float>();
+    return pcrs_launch_transform(ctx, cx, cy, cz, icp->n, rotation, translation, cx, cy, cz);
+}
+
+int pcrs_icp_get_current(pcrs_icp *icp, float *x, float *y, float *z) {
+    if (!icp) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    float *o[3] = {x, y, z};
+    for (int a = 0; a < 3; ++a)
+        if (o[a]) PCRS_TRY(download(ctx, o[a], icp->cur[a].p, icp->n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
+static void result_identity(pcrs_icp_result *r) {
+    std::memset(r, 0, sizeof(*r));
+    r->rotation[0] = r->rotation[4] = r->rotation[8] = 1.0f;
+}
+
+int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float tolerance,
+                 float max_correspondence_distance, pcrs_icp_result *out) {
+    if (!icp || !out) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (mode != PCRS_ICP_POINT_TO_POINT && mode != PCRS_ICP_POINT_TO_PLANE)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "unknown ICP mode %d", mode);
+    result_identity(out);
+    // icp_plane.rs:27-32 comes before the empty-cloud shortcut
+    if (mode == PCRS_ICP_POINT_TO_PLANE && icp->n_normals != icp->m)
+        return pcrs_set_err(ctx, PCRS_ERR_NORMALS_MISMATCH,
+                            "target_normals length (%zu) does not match target cloud length (%zu)",
+                            icp->n_normals, icp->m);
+    if (icp->n == 0 || icp->m == 0) {  // icp.rs:131-139
+        out->converged = (icp->n == 0 && icp->m == 0) ? 1 : 0;
+        return PCRS_OK;
+    }
+    PCRS_TRY(pcrs_icp_reset(icp));
+    float cum_r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, cum_t[3] = {0, 0, 0};
+    float prev_rmse = std::numeric_limits<float>::infinity();
+    float last_rmse = std::numeric_limits<float>::infinity();
+    float last_fitness = 0.0f;
+    bool converged = false;
+    uint32_t num_iterations = 0;
+    double sums[PCRS_ICP_NSUMS];
+    auto metrics = [&](float *rmse, float *fitness) {
+        *rmse = (float)std::sqrt(sums[1] / sums[0]);           // icp.rs:273-282
+        *fitness = (float)(size_t)sums[0] / (float)icp->n;     // icp.rs:170
+    };
+    for (uint32_t iter = 0; iter < max_iterations; ++iter) {
+        num_iterations = iter + 1;
+        PCRS_TRY(pcrs_icp_accumulate(icp, mode, max_correspondence_distance, sums));
+        if (!(sums[0] > 0.0)) break;  // icp.rs:163-165
+        float rmse, fitness;
+        metrics(&rmse, &fitness);
+        last_rmse = rmse;
+        last_fitness = fitness;
+        if (std::fabs(prev_rmse - rmse) < tolerance) {  // icp.rs:173-176
+            converged = true;
+            break;
+        }
+        prev_rmse = rmse;
+        float inc_r[9], inc_t[3];
+        PCRS_TRY(pcrs_icp_solve(mode, sums, inc_r, inc_t));
+        pcrs_host_compose(cum_r, cum_t, inc_r, inc_t, cum_r, cum_t);  // icp.rs:183
+        PCRS_TRY(pcrs_icp_apply(icp, inc_r, inc_t));                  // icp.rs:186
+    }
+    if (num_iterations == 0) {  // icp.rs:190-197
+        PCRS_TRY(pcrs_icp_accumulate(icp, mode, max_correspondence_distance, sums));
+        if (sums[0] > 0.0) metrics(&last_rmse, &last_fitness);
+    }
+    std::memcpy(out->rotation, cum_r, sizeof(cum_r));
+    std::memcpy(out->translation, cum_t, sizeof(cum_t));
+    out->fitness = last_fitness;
+    out->rmse = last_rmse;
+    out->converged = converged ? 1 : 0;
+    out->num_iterations = num_iterations;
+    return PCRS_OK;
+}
+
+int pcrs_icp_register(pcrs_ctx *ctx, int mode, const float *sx, const float *sy, const float *sz, size_t n,
+             const float *tx, const float *ty, const float *tz, size_t m, const float *tnx,
+             const float *tny, const float *tnz, size_t n_normals, uint32_t max_iterations,
+             float tolerance, float max_correspondence_distance, pcrs_icp_result *out) {
+    if (!out) return PCRS_ERR_INVALID_ARG;
+    PCRS_TRY(bind_device(ctx));
+    result_identity(out);
+    if (mode != PCRS_ICP_POINT_TO_POINT && mode != PCRS_ICP_POINT_TO_PLANE)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "unknown ICP mode %d", mode);
+    const bool have_n = tnx && tny && tnz;
+    if (mode == PCRS_ICP_POINT_TO_PLANE && ((have_n ? n_normals : 0) != m))
+        return pcrs_set_err(ctx, PCRS_ERR_NORMALS_MISMATCH,
+                            "target_normals length (%zu) does not match target cloud length (%zu)",
+                            have_n ? n_normals : (size_t)0, m);
+    if (n == 0 || m == 0) {
+        out->converged = (n == 0 && m == 0) ? 1 : 0;
+        return PCRS_OK;
+    }
+    pcrs_icp *icp = nullptr;
+    PCRS_TRY(pcrs_icp_create(ctx, sx, sy, sz, n, tx, ty, tz, m, tnx, tny, tnz, n_normals, &icp));
+    int rc = pcrs_icp_run(icp, mode, max_iterations, tolerance, max_correspondence_distance, out);
+    pcrs_icp_destroy(icp);
+    return rc;
+}
+
+}  // extern "C"
+
+// v1 of the global SOR statistics: bring the means to the host and sum them left to right there,
+// which is the only order that reproduces the reference's f32 threshold bit for bit.
+int pcrs_sor_threshold_impl(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul, float *thr,
+                            int *has_finite) {
+    *thr = std::numeric_limits<float>::quiet_NaN();
+    *has_finite = 0;
+    if (n == 0) return PCRS_OK;
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, n * sizeof(float), &pin));
+    PCRS_TRY(download(ctx, pin, dmean, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    float t;
+    if (host_threshold(reinterpret_cast<const float *>(pin), n, std_mul, &t)) {
+        *thr = t;
+        *has_finite = 1;
+    }
+    return PCRS_OK;
+}

@@ -1,0 +1,279 @@
+// Device-side building blocks shared by the brute-force and grid neighbour kernels:
+// (d2, index) keys, the register top-K list, and the fused per-query consumers
+// (SOR mean distance, PCA normal, list output, 1-NN output).
+#pragma once
+
+#include "pcrs_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace pcrs {
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    // (v - v) is 0 for finite v and NaN for inf/NaN
+    float s = (x - x) + (y - y) + (z - z);
+    return s == 0.0f;
+}
+
+// kiddo SquaredEuclidean fold for f32 x 3 axes: ((dx*dx + dy*dy) + dz*dz), no fma.
+__device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, float py, float pz) {
+    float dx = qx - px;
+    float dy = qy - py;
+    float dz = qz - pz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// Neighbour order: ascending squared distance, then DESCENDING point index.  One unsigned 64-bit
+// compare gives exactly that order: d2 >= 0 so its bit pattern is monotone, and the low word
+// stores (0xFFFFFFFE - index).  The empty key (d2 = +inf, low word all ones) is above every real
+// key because indices stay below 0xFFFFFFFE.
+__device__ __forceinline__ uint64_t make_key(float d2, uint32_t idx) {
+    return ((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)(0xFFFFFFFEu - idx);
+}
+__device__ __forceinline__ float key_d2(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
+__device__ __forceinline__ uint32_t key_idx(uint64_t key) { return 0xFFFFFFFEu - (uint32_t)key; }
+
+// Ascending list of the K smallest keys seen, entirely in registers.
+template <int K>
+struct TopK {
+    uint64_t key[K];
+    float worst;  // d2 of key[K-1]; +inf while the list is not full
+
+    __device__ __forceinline__ void init(bool active) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) key[i] = PCRS_EMPTY_KEY;
+        // an inactive lane can never pass `d2 <= worst` (d2 >= 0 or NaN)
+        worst = active ? __builtin_inff() : -1.0f;
+    }
+
+    // Requires nk < key[K-1].
+    __device__ __forceinline__ void insert(uint64_t nk) {
+#pragma unroll
+        for (int s = K - 1; s > 0; --s) {
+            uint64_t lower = key[s - 1];
+            uint64_t cur = key[s];
+            key[s] = (nk < lower) ? lower : ((nk < cur) ? nk : cur);
+        }
+        key[0] = (nk < key[0]) ? nk : key[0];
+        worst = key_d2(key[K - 1]);  // the empty key decodes to +inf
+    }
+
+    __device__ __forceinline__ void offer(float d2, uint32_t idx) {
+        // NaN d2 (non-finite reference point) fails the compare and is dropped.
+        if (d2 <= worst) {
+            uint64_t nk = make_key(d2, idx);
+            if (nk < key[K - 1]) insert(nk);
+        }
+    }
+
+    __device__ __forceinline__ uint32_t count() const {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) c += (key[i] != PCRS_EMPTY_KEY) ? 1u : 0u;
+        return c;
+    }
+};
+
+// Neighbour accessors for the consumers: `for_each(c, f)` calls f(j, key_j) for j < c in order.
+template <int K>
+struct RegNbrs {
+    const uint64_t (&key)[K];
+    __device__ __forceinline__ explicit RegNbrs(const uint64_t (&k)[K]) : key(k) {}
+    template <class F>
+    __device__ __forceinline__ void for_each(uint32_t c, F f) const {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if ((uint32_t)j < c) f((uint32_t)j, key[j]);
+    }
+};
+
+struct ListNbrs {
+    const uint64_t *key;  // ascending keys of this query in global memory
+    template <class F>
+    __device__ __forceinline__ void for_each(uint32_t c, F f) const {
+        for (uint32_t j = 0; j < c; ++j) f(j, key[j]);
+    }
+};
+
+// crates/normals/src/estimate.rs:139-238 — smallest-|eigenvalue| eigenvector of a symmetric 3x3,
+// f64 inside, written here for the device.
+__device__ inline void smallest_eigvec_3x3(float f00, float f01, float f02, float f11, float f12,
+                                           float f22, float &ox, float &oy, float &oz) {
+    const double a00 = f00, a01 = f01, a02 = f02, a11 = f11, a12 = f12, a22 = f22;
+    const double m = (a00 + a11 + a22) / 3.0;
+    const double b00 = a00 - m, b11 = a11 - m, b22 = a22 - m;
+    const double q = (b00 * (b11 * b22 - a12 * a12) - a01 * (a01 * b22 - a12 * a02) +
+                      a02 * (a01 * a12 - b11 * a02)) /
+                     2.0;
+    const double p =
+        (b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12)) / 6.0;
+    const double pp = (p > 0.0) ? p : 0.0;
+    ox = 0.0f;
+    oy = 0.0f;
+    oz = 1.0f;
+    if (pp < 1e-30) return;
+    double ratio = q / (pp * sqrt(pp));
+    if (ratio < -1.0) ratio = -1.0;
+    if (ratio > 1.0) ratio = 1.0;
+    const double phi = acos(ratio) / 3.0;
+    const double sp = sqrt(pp);
+    const double kFracPi3 = 1.04719755119659774615421446109316763;
+    const double eig0 = m + 2.0 * sp * cos(phi + 2.0 * kFracPi3);
+    const double eig2 = m + 2.0 * sp * cos(phi);
+    const double eig1 = 3.0 * m - eig0 - eig2;
+    double lambda;
+    if (fabs(eig0) <= fabs(eig1) && fabs(eig0) <= fabs(eig2))
+        lambda = eig0;
+    else if (fabs(eig1) <= fabs(eig2))
+        lambda = eig1;
+    else
+        lambda = eig2;
+    const double r00 = a00 - lambda, r11 = a11 - lambda, r22 = a22 - lambda;
+    double ex = a01 * a12 - r11 * a02;
+    double ey = a02 * a01 - a12 * r00;
+    double ez = r00 * r11 - a01 * a01;
+    double len2 = ex * ex + ey * ey + ez * ez;
+    if (len2 < 1e-30) {
+        ex = a01 * r22 - a12 * a02;
+        ey = a02 * a02 - r22 * r00;
+        ez = r00 * a12 - a01 * a02;
+        len2 = ex * ex + ey * ey + ez * ez;
+        if (len2 < 1e-30) {
+            ex = r11 * r22 - a12 * a12;
+            ey = a12 * a02 - r22 * a01;
+            ez = a01 * a12 - r11 * a02;
+            len2 = ex * ex + ey * ey + ez * ez;
+            if (len2 < 1e-30) return;  // (0, 0, 1)
+        }
+    }
+    const double inv = 1.0 / sqrt(len2);
+    ox = (float)(ex * inv);
+    oy = (float)(ey * inv);
+    oz = (float)(ez * inv);
+}
+
+// Per-query consumers.  `cnt` = valid neighbours available (ascending), `qvalid` = finite query,
+// `qo` = output slot, (rx,ry,rz) = reference columns in original order for the normals gather.
+template <class Nbrs>
+__device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvalid, size_t qo,
+                                        float qx, float qy, float qz, const float *rx,
+                                        const float *ry, const float *rz, const KnnOut &o) {
+    if (!qvalid) cnt = 0;
+    if (o.idx || o.dist || o.count) {
+        const uint32_t c = cnt < o.k ? cnt : o.k;
+        if (o.count) o.count[qo] = c;
+        const size_t base = qo * (size_t)o.k;
+        nb.for_each(c, [&](uint32_t j, uint64_t key) {
+            if (o.idx) o.idx[base + j] = key_idx(key);
+            if (o.dist) o.dist[base + j] = sqrtf(key_d2(key));  // kdtree.rs:76
+        });
+        for (uint32_t j = c; j < o.k; ++j) {
+            if (o.idx) o.idx[base + j] = PCRS_NO_INDEX;
+            if (o.dist) o.dist[base + j] = __builtin_nanf("");
+        }
+    }
+    if (o.nn_idx) {
+        uint32_t id = PCRS_NO_INDEX;
+        float d2 = __builtin_inff();
+        nb.for_each(cnt < 1u ? cnt : 1u, [&](uint32_t, uint64_t key) {
+            id = key_idx(key);
+            d2 = key_d2(key);
+        });
+        o.nn_idx[qo] = id;
+        if (o.nn_d2) o.nn_d2[qo] = d2;
+    }
+    if (o.mean) {
+        // statistical_outlier.rs:22-37
+        float mean = __builtin_inff();
+        if (qvalid) {
+            const uint32_t kk = o.k_sor + 1u;
+            const uint32_t c = cnt < kk ? cnt : kk;
+            const uint32_t first = c > 1u ? 1u : 0u;
+            const uint32_t nn = c - first;
+            if (nn > 0u) {
+                float sum = 0.0f;
+                nb.for_each(c, [&](uint32_t j, uint64_t key) {
+                    if (j >= first) sum += sqrtf(key_d2(key));
+                });
+                mean = sum / (float)nn;
+            }
+        }
+        o.mean[qo] = mean;
+    }
+    if (o.nx) {
+        // estimate.rs:45-109
+        const uint32_t c = cnt < o.k_nrm ? cnt : o.k_nrm;
+        float nnx = 0.0f, nny = 0.0f, nnz = 1.0f;
+        if (c >= 1u) {
+            const float count = (float)c;
+            float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+            nb.for_each(c, [&](uint32_t, uint64_t key) {
+                const uint32_t id = key_idx(key);
+                cx += rx[id];
+                cy += ry[id];
+                cz += rz[id];
+            });
+            cx /= count;
+            cy /= count;
+            cz /= count;
+            float c00 = 0.0f, c01 = 0.0f, c02 = 0.0f, c11 = 0.0f, c12 = 0.0f, c22 = 0.0f;
+            nb.for_each(c, [&](uint32_t, uint64_t key) {
+                const uint32_t id = key_idx(key);
+                const float dx = rx[id] - cx;
+                const float dy = ry[id] - cy;
+                const float dz = rz[id] - cz;
+                c00 += dx * dx;
+                c01 += dx * dy;
+                c02 += dx * dz;
+                c11 += dy * dy;
+                c12 += dy * dz;
+                c22 += dz * dz;
+            });
+            smallest_eigvec_3x3(c00, c01, c02, c11, c12, c22, nnx, nny, nnz);
+            const float len = sqrtf((nnx * nnx + nny * nny) + nnz * nnz);
+            if (len > 1e-10f) {
+                nnx /= len;
+                nny /= len;
+                nnz /= len;
+            }
+            const float vx = o.vp[0] - qx, vy = o.vp[1] - qy, vz = o.vp[2] - qz;
+            const float dot = (nnx * vx + nny * vy) + nnz * vz;
+            if (dot < 0.0f) {
+                nnx = -nnx;
+                nny = -nny;
+                nnz = -nnz;
+            }
+        }
+        o.nx[qo] = nnx;
+        o.ny[qo] = nny;
+        o.nz[qo] = nnz;
+    }
+}
+
+// Smallest register bucket that holds `kneed` neighbours (kneed <= PCRS_KMAX_REG).
+inline int k_bucket(uint32_t kneed) {
+    static const int buckets[] = {1, 2, 4, 8, 12, 16, 17, 21, 24, 32, 48, 64};
+    for (int b : buckets)
+        if ((uint32_t)b >= kneed) return b;
+    return 0;
+}
+
+// Expands `call(K)` for the bucket chosen at run time.
+#define PCRS_DISPATCH_K(kb, CALL) \
+    switch (kb) {                 \
+        case 1: CALL(1); break;   \
+        case 2: CALL(2); break;   \
+        case 4: CALL(4); break;   \
+        case 8: CALL(8); break;   \
+        case 12: CALL(12); break; \
+        case 16: CALL(16); break; \
+        case 17: CALL(17); break; \
+        case 21: CALL(21); break; \
+        case 24: CALL(24); break; \
+        case 32: CALL(32); break; \
+        case 48: CALL(48); break; \
+        case 64: CALL(64); break; \
+        default: break;           \
+    }
+
+}  // namespace pcrs

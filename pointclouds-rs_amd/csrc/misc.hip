@@ -1,0 +1,266 @@
+// Streaming kernels around the neighbour search: inlier mask, rigid transform, radius count and
+// the ICP consumer reduction.  All are HBM-bound single passes over SoA columns.
+#include "knn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace pcrs {
+
+// ---------------------------------------------------------------------------------------------
+// keep[i] = mean[i] <= thr  (crates/filters/src/statistical_outlier.rs:64-66); NaN/inf means drop.
+__global__ __launch_bounds__(256) void mask_kernel(const float *__restrict__ mean, size_t n,
+                                                   float thr, uint8_t *__restrict__ keep,
+                                                   unsigned long long *count) {
+    unsigned local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const bool k = mean[i] <= thr;
+        keep[i] = k ? 1 : 0;
+        local += k ? 1u : 0u;
+    }
+    if (!count) return;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    __shared__ unsigned wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (s) atomicAdd(count, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// p' = R p + t, crates/registration/src/icp.rs:39-47: ((r0*x + r1*y) + r2*z) + t, no fma.
+struct Rigid {
+    float r[9];
+    float t[3];
+};
+
+__global__ __launch_bounds__(256) void transform_kernel(const float *x, const float *y,
+                                                        const float *z, size_t n, Rigid T,
+                                                        float *ox, float *oy, float *oz) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float px = x[i], py = y[i], pz = z[i];
+        const float a = T.r[0] * px + T.r[1] * py + T.r[2] * pz + T.t[0];
+        const float b = T.r[3] * px + T.r[4] * py + T.r[5] * pz + T.t[1];
+        const float c = T.r[6] * px + T.r[7] * py + T.r[8] * pz + T.t[2];
+        ox[i] = a;
+        oy[i] = b;
+        oz[i] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Count of reference points with d2 <= r2 per query (kdtree.rs:114-129), LDS-tiled scan.
+constexpr int RC_TILE = 1024;
+__global__ __launch_bounds__(256) void radius_count_kernel(const float *rx, const float *ry,
+                                                           const float *rz, uint32_t m,
+                                                           const float *qx, const float *qy,
+                                                           const float *qz, uint32_t n, float r2,
+                                                           uint32_t *count) {
+    __shared__ __attribute__((aligned(16))) float tx[RC_TILE];
+    __shared__ __attribute__((aligned(16))) float ty[RC_TILE];
+    __shared__ __attribute__((aligned(16))) float tz[RC_TILE];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t qi = blockIdx.x * 256 + tid;
+    float x = 0, y = 0, z = 0;
+    if (qi < n) {
+        x = qx[qi];
+        y = qy[qi];
+        z = qz[qi];
+    }
+    const bool qvalid = qi < n && finite3(x, y, z);
+    uint32_t c = 0;
+    for (uint32_t base = 0; base < m; base += RC_TILE) {
+        __syncthreads();
+        for (int t = tid; t < RC_TILE; t += 256) {
+            const uint32_t g = base + t;
+            float px = __builtin_nanf(""), py = 0, pz = 0;
+            if (g < m) {
+                px = rx[g];
+                py = ry[g];
+                pz = rz[g];
+                if (!finite3(px, py, pz)) px = __builtin_nanf("");
+            }
+            tx[t] = px;
+            ty[t] = py;
+            tz[t] = pz;
+        }
+        __syncthreads();
+        const uint32_t lim = min((uint32_t)RC_TILE, m - base);
+        for (uint32_t j = 0; j < lim; ++j) {
+            const float d2 = sqdist(x, y, z, tx[j], ty[j], tz[j]);
+            c += (d2 <= r2) ? 1u : 0u;
+        }
+    }
+    if (qi < n) count[qi] = qvalid ? c : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ICP consumer reduction.  Stage 1: every block folds its grid-stride share of the source into
+// PCRS_ICP_NSUMS doubles (fixed lane -> wave -> block order); stage 2: one block folds the block
+// partials in block order.  No floating-point atomics, so the result is run-to-run identical.
+constexpr int ICP_THREADS = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
+    const float *cx, const float *cy, const float *cz, uint32_t n, const float *tx,
+    const float *ty, const float *tz, const float *tnx, const float *tny, const float *tnz,
+    const uint32_t *nn_idx, const float *nn_d2, float max_d, uint32_t *tgt_idx_out,
+    float *dist_out, double *partials) {
+    constexpr int NS = (MODE == PCRS_ICP_POINT_TO_PLANE) ? 29 : 17;
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+
+    for (uint32_t i = blockIdx.x * ICP_THREADS + threadIdx.x; i < n;
+         i += gridDim.x * ICP_THREADS) {
+        const uint32_t ti = nn_idx[i];
+        bool valid = ti != PCRS_NO_INDEX;
+        float dist = __builtin_nanf("");
+        if (valid) {
+            dist = sqrtf(nn_d2[i]);  // kdtree.rs:76
+            valid = dist <= max_d;   // correspondence.rs:28
+        }
+        if (tgt_idx_out) tgt_idx_out[i] = valid ? ti : PCRS_NO_INDEX;
+        if (dist_out) dist_out[i] = valid ? dist : __builtin_nanf("");
+        if (!valid) continue;
+        acc[0] += 1.0;
+        acc[1] += (double)(dist * dist);  // icp.rs:279, product rounded to f32
+        const double sx = cx[i], sy = cy[i], sz = cz[i];
+        const double px = tx[ti], py = ty[ti], pz = tz[ti];
+        if (MODE == PCRS_ICP_POINT_TO_PLANE) {
+            // icp_plane.rs:152-179
+            const double nx = tnx[ti], ny = tny[ti], nz = tnz[ti];
+            const double a[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx,
+                                 nx,                ny,                nz};
+            const double b = (px - sx) * nx + (py - sy) * ny + (pz - sz) * nz;
+            int s = 2;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) acc[s++] += a[r] * a[c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[23 + r] += a[r] * b;
+        } else {
+            const double s3[3] = {sx, sy, sz}, t3[3] = {px, py, pz};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                acc[2 + r] += s3[r];
+                acc[5 + r] += t3[r];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[8 + r * 3 + c] += s3[r] * t3[c];
+            }
+        }
+    }
+
+    __shared__ double wsum[ICP_THREADS / 64][NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) wsum[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PCRS_ICP_NSUMS) {
+        double v = 0.0;
+        if ((int)threadIdx.x < NS) {
+            for (int w = 0; w < ICP_THREADS / 64; ++w) v += wsum[w][threadIdx.x];
+        }
+        partials[(size_t)blockIdx.x * PCRS_ICP_NSUMS + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void icp_final_kernel(const double *partials, uint32_t nblocks,
+                                                       double *sums) {
+    const int i = threadIdx.x;
+    if (i >= PCRS_ICP_NSUMS) return;
+    double v = 0.0;
+    for (uint32_t b = 0; b < nblocks; ++b) v += partials[(size_t)b * PCRS_ICP_NSUMS + i];
+    sums[i] = v;
+}
+
+}  // namespace pcrs
+
+using namespace pcrs;
+
+static unsigned stream_grid(pcrs_ctx *ctx, size_t n, int threads) {
+    size_t blocks = (n + threads - 1) / threads;
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint8_t *keep,
+                     unsigned long long *d_count) {
+    if (d_count) PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(*d_count), ctx->stream));
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(mask_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, ctx->stream,
+                       mean, n, thr, keep, d_count);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                          const float rot[9], const float t[3], float *ox, float *oy, float *oz) {
+    if (n == 0) return PCRS_OK;
+    Rigid T;
+    for (int i = 0; i < 9; ++i) T.r[i] = rot[i];
+    for (int i = 0; i < 3; ++i) T.t[i] = t[i];
+    hipLaunchKernelGGL(transform_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, ctx->stream,
+                       x, y, z, n, T, ox, oy, oz);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
+                             size_t m, const float *qx, const float *qy, const float *qz, size_t n,
+                             float radius, uint32_t *count) {
+    if (n == 0) return PCRS_OK;
+    if (m >= 0xFFFFFFFFull || n >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    // kdtree.rs:106-112: empty tree, radius <= 0 or non-finite -> no results
+    if (m == 0 || !(radius > 0.0f) || !(radius - radius == 0.0f)) {
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, n * sizeof(uint32_t), ctx->stream));
+        return PCRS_OK;
+    }
+    const float r2 = radius * radius;  // kdtree.rs:114
+    hipLaunchKernelGGL(radius_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, rx, ry, rz, (uint32_t)m, qx, qy, qz, (uint32_t)n, r2, count);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float *cy,
+                           const float *cz, size_t n, const float *tx, const float *ty,
+                           const float *tz, const float *tnx, const float *tny, const float *tnz,
+                           const uint32_t *nn_idx, const float *nn_d2, float max_d,
+                           uint32_t *tgt_idx_out, float *dist_out, double *d_sums) {
+    if (n == 0) {
+        PCRS_HIP_CHECK(ctx,
+                       hipMemsetAsync(d_sums, 0, PCRS_ICP_NSUMS * sizeof(double), ctx->stream));
+        return PCRS_OK;
+    }
+    size_t blocks = (n + ICP_THREADS - 1) / ICP_THREADS;
+    if (blocks > 1024) blocks = 1024;
+    void *scratch = nullptr;
+    int rc = pcrs_ctx_scratch(ctx, blocks * PCRS_ICP_NSUMS * sizeof(double), &scratch);
+    if (rc != PCRS_OK) return rc;
+    double *partials = reinterpret_cast<double *>(scratch);
+    if (mode == PCRS_ICP_POINT_TO_PLANE)
+        hipLaunchKernelGGL(icp_partial_kernel<PCRS_ICP_POINT_TO_PLANE>, dim3((unsigned)blocks),
+                           dim3(ICP_THREADS), 0, ctx->stream, cx, cy, cz, (uint32_t)n, tx, ty, tz,
+                           tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials);
+    else
+        hipLaunchKernelGGL(icp_partial_kernel<PCRS_ICP_POINT_TO_POINT>, dim3((unsigned)blocks),
+                           dim3(ICP_THREADS), 0, ctx->stream, cx, cy, cz, (uint32_t)n, tx, ty, tz,
+                           tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials);
+    hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partials,
+                       (uint32_t)blocks, d_sums);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}

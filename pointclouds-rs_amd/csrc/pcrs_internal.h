@@ -1,0 +1,171 @@
+// Internal declarations shared by the kernels and the C-ABI layer of libpcrs_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pcrs_hip.h"
+
+// All device arithmetic must keep the reference's f32 operation order: never contract a*b+c.
+#pragma clang fp contract(off)
+
+// (d2 = +inf, index = none): larger than every real key, and decodes to d2 = +inf
+#define PCRS_EMPTY_KEY 0x7F800000FFFFFFFFull
+#define PCRS_KMAX_REG 64  // largest neighbour list kept in registers
+
+struct pcrs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // pinned host staging for small scalar read-backs
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // reusable device scratch (grown on demand, never shrunk)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int num_cus = 256;
+    // optional HIP-event bracketing of the neighbour-search kernel (benchmark instrumentation)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;  // one pair per bracketed launch
+    size_t ev_used = 0;
+};
+
+// Brackets one launch of the dominant (neighbour-search) kernel with HIP events on the context's
+// stream when timing is enabled; no-ops otherwise.
+void pcrs_timing_begin(pcrs_ctx *ctx);
+void pcrs_timing_end(pcrs_ctx *ctx);
+
+int pcrs_set_err(pcrs_ctx *ctx, int code, const char *fmt, ...);
+// grows the context's device scratch / pinned staging; returns PCRS_OK or an error code
+int pcrs_ctx_scratch(pcrs_ctx *ctx, size_t bytes, void **out);
+int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out);
+
+#define PCRS_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return pcrs_set_err((ctx), _e == hipErrorOutOfMemory ? PCRS_ERR_OOM : PCRS_ERR_HIP, \
+                                "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),          \
+                                __FILE__, __LINE__);                                           \
+    } while (0)
+
+// Simple owning device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t alloc(size_t b) {
+        release();
+        if (b == 0) b = 16;
+        hipError_t e = hipMalloc(&p, b);
+        if (e == hipSuccess) bytes = b;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// Uniform grid over the finite points of a cloud (counting-sorted copy).
+struct GridGeom {
+    float ox, oy, oz;   // origin (min corner of finite points)
+    float cell, inv;    // cell edge and its reciprocal
+    int nx, ny, nz;     // cells per axis
+    float slack;        // absolute safety margin covering f32 rounding of cell assignment
+};
+
+struct pcrs_index {
+    pcrs_ctx *ctx = nullptr;
+    const float *x = nullptr, *y = nullptr, *z = nullptr;  // device columns (original order)
+    size_t m = 0;
+    DevBuf own_x, own_y, own_z;  // set when built from host memory
+    int algo = PCRS_ALGO_BRUTE;  // resolved strategy (BRUTE or GRID)
+    // grid (algo == GRID)
+    GridGeom g{};
+    size_t nvalid = 0;       // finite points
+    uint32_t ncell = 0;
+    DevBuf cell_start;       // uint32 [ncell + 1] into the sorted arrays
+    DevBuf sx, sy, sz;       // float  [nvalid] sorted by cell
+    DevBuf sidx;             // uint32 [nvalid] original index of sorted slot
+    DevBuf slot_of;          // uint32 [m] sorted slot of original point (PCRS_NO_INDEX if non-finite)
+    // block decomposition for the tile kernel
+    int bx = 2, by = 2, bz = 2;  // cells per query block
+    uint64_t stats[3] = {0, 0, 0};
+};
+
+// Output selection of a neighbour search.  Every pointer is nullable.
+struct KnnOut {
+    // KNN list output
+    uint32_t *idx = nullptr;    // [nq * k]
+    float *dist = nullptr;      // [nq * k]
+    uint32_t *count = nullptr;  // [nq]
+    uint32_t k = 0;             // neighbours requested for the list output
+    // statistical-outlier mean distance (ranks 1..k_sor of a (k_sor+1)-NN list)
+    float *mean = nullptr;  // [nq]
+    uint32_t k_sor = 0;
+    // PCA normals (ranks 0..k_nrm-1)
+    float *nx = nullptr, *ny = nullptr, *nz = nullptr;  // [nq]
+    uint32_t k_nrm = 0;
+    float vp[3] = {0, 0, 0};
+    // 1-NN correspondence
+    uint32_t *nn_idx = nullptr;  // [nq]
+    float *nn_d2 = nullptr;      // [nq] squared distance, +inf when none
+};
+
+// Query description: either explicit query columns or a self-query range of the indexed cloud.
+struct KnnQuery {
+    const float *qx = nullptr, *qy = nullptr, *qz = nullptr;
+    size_t nq = 0;
+    size_t out_offset = 0;  // self queries: first query is point out_offset of the cloud
+    bool self = false;
+};
+
+// ---- brute force (knn_bf.hip)
+// Searches all m reference points for each query.  qlist (nullable) restricts the work to the
+// listed query positions; its length is read from *qlist_count on the device.
+int pcrs_launch_knn_bf(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz, size_t m,
+                       const KnnQuery &q, const KnnOut &out, uint32_t kneed,
+                       const uint32_t *qlist, const uint32_t *qlist_count, size_t qlist_cap);
+
+// ---- grid (grid.hip)
+int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint);
+int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed);
+
+// ---- misc kernels (misc.hip)
+int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint8_t *keep,
+                     unsigned long long *d_count);
+int pcrs_launch_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                          const float rot[9], const float t[3], float *ox, float *oy, float *oz);
+int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
+                             size_t m, const float *qx, const float *qy, const float *qz, size_t n,
+                             float radius, uint32_t *count);
+// ICP consumer reduction over dense correspondences (nn_idx / nn_d2 per source point).
+// partials: device scratch of PCRS_ICP_NSUMS doubles per block; result in d_sums[PCRS_ICP_NSUMS].
+int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float *cy,
+                           const float *cz, size_t n, const float *tx, const float *ty,
+                           const float *tz, const float *tnx, const float *tny, const float *tnz,
+                           const uint32_t *nn_idx, const float *nn_d2, float max_d,
+                           uint32_t *tgt_idx_out, float *dist_out, double *d_sums);
+// exact reproduction of a left-to-right f32 sum (stats.hip)
+int pcrs_sor_threshold_impl(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
+                            float *thr, int *has_finite);
+
+// ---- host math (host_math.cpp)
+void pcrs_host_compose(const float ra[9], const float ta[3], const float rb[9], const float tb[3],
+                       float ro[9], float to[3]);
+void pcrs_host_solve_plane(const double *sums, float rot[9], float t[3]);
+void pcrs_host_solve_point(const double *sums, float rot[9], float t[3]);

@@ -1,0 +1,225 @@
+"""`pointclouds_rs`-compatible Python surface for the KNN hot path, running on MI355X.
+
+Mirrors the PyO3 module of the reference (crates/python/src/lib.rs:12-49) for the
+functions on the accelerated path — same names, argument order, defaults and
+error types:
+
+    PointCloud                                  crates/python/src/cloud.rs:4-88
+    statistical_outlier_removal(cloud, k, std_mul)      .../filters.rs:36-49
+    radius_outlier_removal(cloud, radius, min_neighbors) .../filters.rs:51-64
+    estimate_normals(cloud, k)                          .../normals.rs:4-10
+    icp_point_to_point / icp_point_to_plane / apply_transform / IcpResult
+                                                        .../registration.rs:4-109
+
+Functions of the reference module that are not on this path (voxel_downsample,
+passthrough_filter, ransac_plane, euclidean_cluster, file I/O) are not provided.
+Everything computes through libpcrs_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _ffi, hip
+
+__all__ = [
+    "PointCloud",
+    "IcpResult",
+    "statistical_outlier_removal",
+    "radius_outlier_removal",
+    "estimate_normals",
+    "icp_point_to_point",
+    "icp_point_to_plane",
+    "apply_transform",
+]
+
+
+class PointCloud:
+    """SoA point cloud (crates/core/src/cloud.rs:3-11) with the PyO3 class's methods."""
+
+    def __init__(self):
+        self._x = np.empty(0, dtype=np.float32)
+        self._y = np.empty(0, dtype=np.float32)
+        self._z = np.empty(0, dtype=np.float32)
+        self._normals = None  # (nx, ny, nz) or None, as PointCloud.normals: Option<Normals>
+
+    @classmethod
+    def _from_columns(cls, x, y, z, normals=None):
+        pc = cls()
+        pc._x = np.ascontiguousarray(x, dtype=np.float32)
+        pc._y = np.ascontiguousarray(y, dtype=np.float32)
+        pc._z = np.ascontiguousarray(z, dtype=np.float32)
+        pc._normals = normals
+        return pc
+
+    @staticmethod
+    def from_numpy(array):
+        # crates/python/src/cloud.rs:25-37,91-137
+        if not isinstance(array, np.ndarray) or array.dtype not in (np.float32, np.float64):
+            raise TypeError("expected NumPy array with dtype float32 or float64, shape (N, 3)")
+        if array.ndim != 2:
+            raise TypeError("expected NumPy array with dtype float32 or float64, shape (N, 3)")
+        if not array.flags["C_CONTIGUOUS"]:
+            raise ValueError(
+                "array must be C-contiguous (row-major). Use numpy.ascontiguousarray(arr) to convert."
+            )
+        if array.shape[1] != 3:
+            raise ValueError("expected shape (N, 3)")
+        a = array.astype(np.float32, copy=False)
+        return PointCloud._from_columns(a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy())
+
+    def len(self):
+        return len(self._x)
+
+    def is_empty(self):
+        return len(self._x) == 0
+
+    def to_numpy(self):
+        return np.stack([self._x, self._y, self._z], axis=1) if len(self._x) else np.empty(
+            (0, 3), dtype=np.float32)
+
+    def _check_indices(self, indices):
+        idx = np.asarray(list(indices), dtype=np.int64)
+        if idx.size and (idx.min() < 0 or idx.max() >= len(self._x)):
+            bad = int(idx[(idx < 0) | (idx >= len(self._x))][0])
+            raise IndexError(f"index {bad} out of bounds for cloud with {len(self._x)} points")
+        return idx
+
+    def select(self, indices):
+        # crates/core/src/cloud.rs:103-140 (normals travel with the points)
+        idx = self._check_indices(indices)
+        normals = None
+        if self._normals is not None:
+            normals = tuple(c[idx] for c in self._normals)
+        return PointCloud._from_columns(self._x[idx], self._y[idx], self._z[idx], normals)
+
+    def select_inverse(self, indices):
+        # crates/core/src/cloud.rs:152-162
+        idx = self._check_indices(indices)
+        keep = np.ones(len(self._x), dtype=bool)
+        keep[idx] = False
+        return self.select(np.nonzero(keep)[0])
+
+    def __len__(self):
+        return len(self._x)
+
+    def __repr__(self):
+        return f"PointCloud(n={len(self._x)})"
+
+    # Extension (the reference class has no getter for normals): (N, 3) array or None.
+    def normals_numpy(self):
+        if self._normals is None:
+            return None
+        return np.stack(self._normals, axis=1)
+
+
+class IcpResult:
+    """crates/python/src/registration.rs:4-29"""
+
+    def __init__(self, converged, fitness, rmse, num_iterations, translation, rotation):
+        self.converged = bool(converged)
+        self.fitness = float(fitness)
+        self.rmse = float(rmse)
+        self.num_iterations = int(num_iterations)
+        self.translation = [float(v) for v in translation]
+        self.rotation = [[float(rotation[r * 3 + c]) for c in range(3)] for r in range(3)]
+
+    def __repr__(self):
+        return (f"IcpResult(converged={'true' if self.converged else 'false'}, "
+                f"rmse={self.rmse:.6f}, iterations={self.num_iterations})")
+
+
+def _require_cloud(c, name="cloud"):
+    if not isinstance(c, PointCloud):
+        raise TypeError(f"argument '{name}': expected PointCloud")
+
+
+def statistical_outlier_removal(cloud, k, std_mul):
+    """crates/python/src/filters.rs:36-49 -> crates/filters/src/statistical_outlier.rs:4-69"""
+    _require_cloud(cloud)
+    if k < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    std_mul = float(std_mul)
+    if not math.isfinite(std_mul) or std_mul < 0.0:
+        raise ValueError("std_mul must be >= 0 and finite")
+    keep, _, _, _ = hip.sor(cloud._x, cloud._y, cloud._z, int(k), std_mul)
+    return cloud.select(np.nonzero(keep)[0])
+
+
+def radius_outlier_removal(cloud, radius, min_neighbors):
+    """crates/python/src/filters.rs:51-64 -> crates/filters/src/radius_outlier.rs:4-18"""
+    _require_cloud(cloud)
+    radius = float(radius)
+    if not math.isfinite(radius) or radius <= 0.0:
+        raise ValueError("radius must be > 0 and finite")
+    if cloud.is_empty():
+        return PointCloud()
+    ix = hip.Index(cloud._x, cloud._y, cloud._z)
+    try:
+        count = ix.radius_count(cloud._x, cloud._y, cloud._z, radius)
+    finally:
+        ix.close()
+    return cloud.select(np.nonzero(count >= int(min_neighbors))[0])
+
+
+def estimate_normals(cloud, k):
+    """crates/python/src/normals.rs:4-10: returns a copy of the cloud with normals attached."""
+    _require_cloud(cloud)
+    if k < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    nx, ny, nz = hip.normals(cloud._x, cloud._y, cloud._z, int(k), (0.0, 0.0, 0.0))
+    return PointCloud._from_columns(cloud._x.copy(), cloud._y.copy(), cloud._z.copy(), (nx, ny, nz))
+
+
+def _icp(mode, source, target, normals, max_iterations, tolerance, max_correspondence_distance):
+    res = hip.icp_register(
+        mode,
+        (source._x, source._y, source._z),
+        (target._x, target._y, target._z),
+        normals,
+        int(max_iterations),
+        float(tolerance),
+        float(max_correspondence_distance),
+    )
+    return IcpResult(res.converged, res.fitness, res.rmse, res.num_iterations,
+                     list(res.translation), list(res.rotation))
+
+
+def icp_point_to_point(source, target, max_iterations=50, tolerance=1e-5,
+                       max_correspondence_distance=math.inf):
+    """crates/python/src/registration.rs:31-55"""
+    _require_cloud(source, "source")
+    _require_cloud(target, "target")
+    return _icp(_ffi.ICP_POINT_TO_POINT, source, target, None, max_iterations, tolerance,
+                max_correspondence_distance)
+
+
+def icp_point_to_plane(source, target, max_iterations=50, tolerance=1e-5,
+                       max_correspondence_distance=math.inf):
+    """crates/python/src/registration.rs:57-95"""
+    _require_cloud(source, "source")
+    _require_cloud(target, "target")
+    if target._normals is None:
+        raise ValueError("target cloud must have normals for point-to-plane ICP. "
+                         "Use estimate_normals(target, k) first.")
+    try:
+        return _icp(_ffi.ICP_POINT_TO_PLANE, source, target, target._normals, max_iterations,
+                    tolerance, max_correspondence_distance)
+    except _ffi.PcrsError as e:
+        if e.code == _ffi.PCRS_ERR_NORMALS_MISMATCH:
+            raise ValueError(e.message) from None
+        raise
+
+
+def apply_transform(cloud, rotation, translation):
+    """crates/python/src/registration.rs:97-109 (drops normals, icp.rs:91)"""
+    _require_cloud(cloud)
+    r = np.asarray(rotation, dtype=np.float32)
+    t = np.asarray(translation, dtype=np.float32)
+    if r.shape != (3, 3) or t.shape != (3,):
+        raise TypeError("rotation must be 3x3 and translation length 3")
+    if cloud.is_empty():
+        return PointCloud()
+    x, y, z = hip.apply_transform(cloud._x, cloud._y, cloud._z, r, t)
+    return PointCloud._from_columns(x, y, z)

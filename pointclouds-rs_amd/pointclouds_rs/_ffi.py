@@ -1,0 +1,164 @@
+"""ctypes binding of libpcrs_hip.so (declarations follow include/pcrs_hip.h one to one).
+
+There is no CPU fallback: if the library is missing, or no GPU is present when a
+context is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libpcrs_hip.so"))
+
+PCRS_OK = 0
+PCRS_ERR_INVALID_ARG = -1
+PCRS_ERR_HIP = -2
+PCRS_ERR_OOM = -3
+PCRS_ERR_NORMALS_MISMATCH = -4
+NO_INDEX = 0xFFFFFFFF
+ICP_POINT_TO_POINT = 0
+ICP_POINT_TO_PLANE = 1
+ALGO_AUTO, ALGO_BRUTE, ALGO_GRID = 0, 1, 2
+ICP_NSUMS = 32
+
+c_float_p = C.POINTER(C.c_float)
+c_u32_p = C.POINTER(C.c_uint32)
+c_u8_p = C.POINTER(C.c_uint8)
+c_f64_p = C.POINTER(C.c_double)
+c_size_p = C.POINTER(C.c_size_t)
+
+
+class IcpResultC(C.Structure):
+    _fields_ = [
+        ("rotation", C.c_float * 9),
+        ("translation", C.c_float * 3),
+        ("fitness", C.c_float),
+        ("rmse", C.c_float),
+        ("converged", C.c_int32),
+        ("num_iterations", C.c_uint32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/pcrs_hip.h declares
+_V = C.c_void_p
+_F3 = [_V, _V, _V]  # three column pointers (host or device)
+SIGNATURES = {
+    "pcrs_ctx_create": (C.c_int, [C.c_int, C.POINTER(_V)]),
+    "pcrs_ctx_set_stream": (C.c_int, [_V, _V]),
+    "pcrs_ctx_destroy": (None, [_V]),
+    "pcrs_last_error": (C.c_char_p, [_V]),
+    "pcrs_ctx_synchronize": (C.c_int, [_V]),
+    "pcrs_version": (C.c_char_p, []),
+    "pcrs_index_build": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_int, C.POINTER(_V)]),
+    "pcrs_index_build_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_int, C.POINTER(_V)]),
+    "pcrs_index_destroy": (None, [_V]),
+    "pcrs_index_len": (C.c_size_t, [_V]),
+    "pcrs_knn_batch": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, _V, _V, _V]),
+    "pcrs_knn_batch_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, _V, _V, _V]),
+    "pcrs_radius_count": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V]),
+    "pcrs_radius_count_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V]),
+    "pcrs_sor_mean_dist_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, _V]),
+    "pcrs_sor_threshold_dev": (C.c_int, [_V, _V, C.c_size_t, C.c_float, c_float_p, C.POINTER(C.c_int)]),
+    "pcrs_sor_mask_dev": (C.c_int, [_V, _V, C.c_size_t, C.c_float, _V, c_size_p]),
+    "pcrs_sor": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_float, _V, c_size_p, c_float_p, _V]),
+    "pcrs_normals_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, c_float_p, _V, _V, _V]),
+    "pcrs_sor_normals_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, c_float_p, _V, _V, _V, _V]),
+    "pcrs_normals": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, c_float_p, _V, _V, _V]),
+    "pcrs_sor_normals": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_float, C.c_uint32, c_float_p, _V, c_size_p, c_float_p, _V, _V, _V]),
+    "pcrs_apply_transform": (C.c_int, [_V] + _F3 + [C.c_size_t, c_float_p, c_float_p, _V, _V, _V]),
+    "pcrs_apply_transform_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, c_float_p, c_float_p, _V, _V, _V]),
+    "pcrs_compose": (None, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "pcrs_find_correspondences": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V, _V, c_size_p]),
+    "pcrs_find_correspondences_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V, _V, c_size_p]),
+    "pcrs_icp_create": (C.c_int, [_V] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t, C.POINTER(_V)]),
+    "pcrs_icp_create_dev": (C.c_int, [_V] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t, C.POINTER(_V)]),
+    "pcrs_icp_destroy": (None, [_V]),
+    "pcrs_icp_reset": (C.c_int, [_V]),
+    "pcrs_icp_accumulate": (C.c_int, [_V, C.c_int, C.c_float, c_f64_p]),
+    "pcrs_icp_solve": (C.c_int, [C.c_int, c_f64_p, c_float_p, c_float_p]),
+    "pcrs_icp_apply": (C.c_int, [_V, c_float_p, c_float_p]),
+    "pcrs_icp_get_current": (C.c_int, [_V, _V, _V, _V]),
+    "pcrs_icp_run": (C.c_int, [_V, C.c_int, C.c_uint32, C.c_float, C.c_float, C.POINTER(IcpResultC)]),
+    "pcrs_icp_register": (C.c_int, [_V, C.c_int] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t, C.c_uint32, C.c_float, C.c_float, C.POINTER(IcpResultC)]),
+    "pcrs_index_last_stats": (C.c_int, [_V, C.POINTER(C.c_uint64)]),
+    "pcrs_ctx_timing": (C.c_int, [_V, C.c_int]),
+    "pcrs_ctx_timing_read": (C.c_int, [_V, c_f64_p, C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Loads libpcrs_hip.so (built in-tree by `make -C csrc`) and declares every entry point."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C pointclouds-rs_amd/csrc` "
+                "(there is no CPU fallback)"
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class PcrsError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"pcrs error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class Context:
+    """One pcrs_ctx (one device, one stream)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.pcrs_ctx_create(device, C.byref(h))
+        if rc != PCRS_OK:
+            raise PcrsError(rc, f"pcrs_ctx_create(device={device}) failed (is a GPU visible?)")
+        self.handle = h
+        self.device = device
+
+    def check(self, rc: int):
+        if rc != PCRS_OK:
+            msg = self.lib.pcrs_last_error(self.handle)
+            raise PcrsError(rc, msg.decode() if msg else "")
+
+    def set_stream(self, stream_ptr: int):
+        self.check(self.lib.pcrs_ctx_set_stream(self.handle, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(self.lib.pcrs_ctx_synchronize(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.lib.pcrs_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def get_context(device: int = 0) -> Context:
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _contexts[device] = ctx
+    return ctx

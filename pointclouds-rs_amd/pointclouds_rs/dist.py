@@ -1,0 +1,286 @@
+"""Query-sharded SOR + normals and ICP across the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank owns a
+contiguous index range of the cloud, resident in its HBM:
+
+  1. all-gather the three SoA columns, so every rank holds the whole reference cloud
+     (100 M points = 1.2 GB, far below 288 GB);
+  2. build the search index over the whole cloud and answer the rank's own queries
+     (fused SOR mean distance + normals, one neighbour search);
+  3. all-gather the per-point mean distances (4 B/pt); every rank derives the same global
+     threshold with the reference's summation order and masks its own range.
+
+ICP shards the source; each iteration all-reduces the PCRS_ICP_NSUMS f64 partial sums and every
+rank solves the same small system, so no transform broadcast is needed.
+
+The numeric work is done by an `engine` object; HipEngine drives libpcrs_hip.so through its
+device-pointer entry points.  (Tests of the sharding logic inject a CPU engine.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _ffi
+
+_V = C.c_void_p
+
+
+def shard_range(n_total: int, world: int, rank: int):
+    """Contiguous [begin, end) of rank's queries; concatenating ranks restores input order."""
+    base, rem = divmod(n_total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class HipEngine:
+    """Device-pointer entry points of libpcrs_hip.so over torch CUDA tensors."""
+
+    def __init__(self, device_index: int = 0, use_torch_stream: bool = True):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        self.ctx = _ffi.get_context(device_index)
+        if use_torch_stream:
+            self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.lib = self.ctx.lib
+
+    # -- tensors
+    def empty(self, n, dtype="float32"):
+        return self.torch.empty(n, dtype=getattr(self.torch, dtype), device=self.device)
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    @staticmethod
+    def _p(t):
+        return _V(t.data_ptr()) if t is not None and t.numel() else _V(None)
+
+    # -- index
+    def build_index(self, x, y, z, k_hint=0, algo=_ffi.ALGO_AUTO):
+        h = _V()
+        self.ctx.check(self.lib.pcrs_index_build_dev(self.ctx.handle, self._p(x), self._p(y),
+                                                     self._p(z), x.numel(), k_hint, algo,
+                                                     C.byref(h)))
+        return h
+
+    def destroy_index(self, h):
+        self.lib.pcrs_index_destroy(h)
+
+    def index_stats(self, h):
+        s = (C.c_uint64 * 3)()
+        self.ctx.check(self.lib.pcrs_index_last_stats(h, s))
+        return [int(v) for v in s]
+
+    # -- fused consumers over a query range
+    def sor_normals_range(self, index, q_begin, q_count, k_sor, k_nrm, viewpoint, mean, nx, ny, nz):
+        vp = (C.c_float * 3)(*[float(v) for v in viewpoint])
+        self.ctx.check(self.lib.pcrs_sor_normals_dev(index, q_begin, q_count, k_sor, k_nrm, vp,
+                                                     self._p(mean), self._p(nx), self._p(ny),
+                                                     self._p(nz)))
+
+    def threshold(self, mean_full, std_mul):
+        thr = C.c_float()
+        ok = C.c_int()
+        self.ctx.check(self.lib.pcrs_sor_threshold_dev(self.ctx.handle, self._p(mean_full),
+                                                       mean_full.numel(), float(std_mul),
+                                                       C.byref(thr), C.byref(ok)))
+        return float(thr.value), bool(ok.value)
+
+    def mask(self, mean, thr, keep, want_count=True):
+        nk = C.c_size_t(0)
+        self.ctx.check(self.lib.pcrs_sor_mask_dev(self.ctx.handle, self._p(mean), mean.numel(),
+                                                  float(thr), self._p(keep),
+                                                  C.byref(nk) if want_count else None))
+        return int(nk.value)
+
+    # -- timing of the neighbour-search kernel
+    def timing(self, enable):
+        self.ctx.check(self.lib.pcrs_ctx_timing(self.ctx.handle, 1 if enable else 0))
+
+    def timing_read(self):
+        ms = C.c_double()
+        n = C.c_uint64()
+        self.ctx.check(self.lib.pcrs_ctx_timing_read(self.ctx.handle, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    # -- ICP
+    def icp_create(self, src, tgt, normals):
+        h = _V()
+        nn = normals if normals is not None else (None, None, None)
+        n_normals = normals[0].numel() if normals is not None else 0
+        self.ctx.check(self.lib.pcrs_icp_create_dev(
+            self.ctx.handle, *[self._p(c) for c in src], src[0].numel(),
+            *[self._p(c) for c in tgt], tgt[0].numel(), *[self._p(c) for c in nn], n_normals,
+            C.byref(h)))
+        return h
+
+    def icp_destroy(self, h):
+        self.lib.pcrs_icp_destroy(h)
+
+    def icp_reset(self, h):
+        self.ctx.check(self.lib.pcrs_icp_reset(h))
+
+    def icp_accumulate(self, h, mode, max_d):
+        sums = np.zeros(_ffi.ICP_NSUMS, dtype=np.float64)
+        self.ctx.check(self.lib.pcrs_icp_accumulate(h, mode, float(max_d),
+                                                    sums.ctypes.data_as(_ffi.c_f64_p)))
+        return sums
+
+    def icp_solve(self, mode, sums):
+        rot = (C.c_float * 9)()
+        t = (C.c_float * 3)()
+        rc = self.lib.pcrs_icp_solve(mode, sums.ctypes.data_as(_ffi.c_f64_p), rot, t)
+        if rc != 0:
+            raise _ffi.PcrsError(rc, "pcrs_icp_solve")
+        return rot, t
+
+    def icp_apply(self, h, rot, t):
+        self.ctx.check(self.lib.pcrs_icp_apply(h, rot, t))
+
+    def icp_run(self, h, mode, max_iter, tol, max_d):
+        res = _ffi.IcpResultC()
+        self.ctx.check(self.lib.pcrs_icp_run(h, mode, max_iter, float(tol), float(max_d),
+                                             C.byref(res)))
+        return res
+
+    def compose(self, ra, ta, rb, tb):
+        ro = (C.c_float * 9)()
+        to = (C.c_float * 3)()
+        self.lib.pcrs_compose(ra, ta, rb, tb, ro, to)
+        return ro, to
+
+
+class Collectives:
+    """torch.distributed wrappers; identity when the job has a single rank."""
+
+    def __init__(self, dist=None):
+        self.dist = dist if (dist is not None and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+
+    def all_gather_var(self, torch, local, counts):
+        """Concatenation over ranks of 1-D tensors whose lengths are `counts` (known everywhere)."""
+        if self.world == 1:
+            return local
+        outs = [torch.empty(c, dtype=local.dtype, device=local.device) for c in counts]
+        self.dist.all_gather(outs, local.contiguous())
+        return torch.cat(outs)
+
+    def all_reduce_sum_f64(self, torch, arr, device):
+        """Sums a small float64 NumPy vector over ranks (rank-order independent result)."""
+        if self.world == 1:
+            return arr
+        # gather then add in rank order, so every rank obtains bit-identical sums
+        t = torch.from_numpy(arr.copy()).to(device)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        acc = np.zeros_like(arr)
+        for o in outs:
+            acc = acc + o.cpu().numpy()
+        return acc
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+
+def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
+                        viewpoint=(0.0, 0.0, 0.0), outputs=None, algo=_ffi.ALGO_AUTO):
+    """SOR + normals of a cloud whose points are sharded over ranks in index order.
+
+    shard: (x, y, z) tensors of this rank's points.  Returns a dict with this rank's
+    keep mask, means, normals, the global threshold and kept count of the shard.
+    `outputs` may carry preallocated tensors (mean, keep, nx, ny, nz) to avoid allocation.
+    """
+    torch = engine.torch
+    world, rank = coll.world, coll.rank
+    counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0]
+              for r in range(world)]
+    begin, end = shard_range(n_total, world, rank)
+    nq = end - begin
+    assert shard[0].numel() == nq, "shard length does not match its index range"
+    full = [coll.all_gather_var(torch, c, counts) for c in shard]
+    if outputs is None:
+        outputs = {}
+    mean = outputs.get("mean") if outputs.get("mean") is not None else engine.empty(nq)
+    keep = outputs.get("keep") if outputs.get("keep") is not None else engine.empty(nq, "uint8")
+    want_n = k_nrm > 0
+    nx = ny = nz = None
+    if want_n:
+        nx = outputs.get("nx") if outputs.get("nx") is not None else engine.empty(nq)
+        ny = outputs.get("ny") if outputs.get("ny") is not None else engine.empty(nq)
+        nz = outputs.get("nz") if outputs.get("nz") is not None else engine.empty(nq)
+    k_hint = max(k_sor + 1 if k_sor else 0, k_nrm)
+    index = engine.build_index(full[0], full[1], full[2], k_hint, algo)
+    try:
+        engine.sor_normals_range(index, begin, nq, k_sor, k_nrm, viewpoint,
+                                 mean if k_sor else None, nx, ny, nz)
+        stats = engine.index_stats(index)
+    finally:
+        engine.destroy_index(index)
+    result = dict(mean=mean, keep=keep, nx=nx, ny=ny, nz=nz, thr=math.nan, n_keep=0, stats=stats,
+                  begin=begin, end=end)
+    if k_sor:
+        mean_full = coll.all_gather_var(torch, mean, counts)
+        thr, ok = engine.threshold(mean_full, std_mul)
+        if ok:
+            result["thr"] = thr
+            result["n_keep"] = engine.mask(mean, thr, keep)
+        else:
+            keep.zero_()
+    return result
+
+
+def icp_sharded(engine, coll, mode, src_shard, n_src_total, tgt, tgt_normals, max_iterations=50,
+                tolerance=1e-5, max_correspondence_distance=math.inf):
+    """ICP with the source sharded over ranks and the target replicated
+    (loop of crates/registration/src/icp.rs:125-206 / icp_plane.rs:20-97)."""
+    torch = engine.torch
+    ident_r = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    ident_t = (C.c_float * 3)(0, 0, 0)
+    out = dict(rotation=ident_r, translation=ident_t, fitness=0.0, rmse=0.0, converged=False,
+               num_iterations=0)
+    if n_src_total == 0 or tgt[0].numel() == 0:
+        out["converged"] = n_src_total == 0 and tgt[0].numel() == 0
+        return out
+    h = engine.icp_create(src_shard, tgt, tgt_normals)
+    try:
+        engine.icp_reset(h)
+        cum_r, cum_t = ident_r, ident_t
+        prev_rmse, last_rmse, last_fit = math.inf, math.inf, 0.0
+        converged, num_it = False, 0
+
+        def metrics(s):
+            rmse = float(np.float32(math.sqrt(s[1] / s[0])))
+            fit = float(np.float32(np.float32(int(s[0])) / np.float32(n_src_total)))
+            return rmse, fit
+
+        for it in range(max_iterations):
+            num_it = it + 1
+            s = engine.icp_accumulate(h, mode, max_correspondence_distance)
+            s = coll.all_reduce_sum_f64(torch, s, engine.device)
+            if not s[0] > 0:
+                break
+            rmse, fit = metrics(s)
+            last_rmse, last_fit = rmse, fit
+            if abs(np.float32(prev_rmse) - np.float32(rmse)) < np.float32(tolerance):
+                converged = True
+                break
+            prev_rmse = rmse
+            inc_r, inc_t = engine.icp_solve(mode, s)
+            cum_r, cum_t = engine.compose(cum_r, cum_t, inc_r, inc_t)
+            engine.icp_apply(h, inc_r, inc_t)
+        if num_it == 0:
+            s = coll.all_reduce_sum_f64(torch, engine.icp_accumulate(h, mode, max_correspondence_distance),
+                                        engine.device)
+            if s[0] > 0:
+                last_rmse, last_fit = metrics(s)
+        out.update(rotation=cum_r, translation=cum_t, fitness=last_fit, rmse=last_rmse,
+                   converged=converged, num_iterations=num_it)
+        return out
+    finally:
+        engine.icp_destroy(h)

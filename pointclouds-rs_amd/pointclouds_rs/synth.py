@@ -1,0 +1,93 @@
+"""Deterministic synthetic clouds for the tests and the benchmark (shapes follow the reference's
+benches and integration tests; the PRNG is SplitMix64 so the data does not depend on a library
+version — the reference's `StdRng` stream cannot be reproduced without the `rand` crate)."""
+import numpy as np
+
+F = np.float32
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed, n, stream=0):
+    """n uint64 values: element i is SplitMix64's (i+1)-th output for state seed + stream * 2^32."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        s = np.uint64(seed) + np.uint64(stream) * np.uint64(1 << 32)
+        z = s + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed, n, stream=0):
+    """float32 in [0, 1) with 24 random bits."""
+    return ((splitmix64(seed, n, stream) >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))).astype(F)
+
+
+def uniform(seed, n, lo, hi, stream=0):
+    return (F(lo) + uniform01(seed, n, stream) * F(hi - lo)).astype(F)
+
+
+def uniform_cloud(n, seed=42, lo=0.0, hi=100.0):
+    """benches/bench_filters.rs:9-15 shape: n points uniform in [lo, hi)^3."""
+    return (uniform(seed, n, lo, hi, 0), uniform(seed, n, lo, hi, 1), uniform(seed, n, lo, hi, 2))
+
+
+def hemisphere(n, seed, radius):
+    """tests/real_world_pipeline.rs:58-80: rejection-sampled upper hemisphere of the given radius."""
+    xs, ys = [], []
+    got, stream = 0, 0
+    while got < n:
+        m = max(2 * (n - got), 64)
+        px = uniform(seed, m, -1.0, 1.0, 10 + 2 * stream)
+        py = uniform(seed, m, -1.0, 1.0, 11 + 2 * stream)
+        ok = (px * px + py * py) < F(1.0)
+        xs.append(px[ok])
+        ys.append(py[ok])
+        got += int(ok.sum())
+        stream += 1
+    px = np.concatenate(xs)[:n]
+    py = np.concatenate(ys)[:n]
+    pz = np.sqrt(F(1.0) - (px * px + py * py)).astype(F)
+    r = F(radius)
+    return (px * r).astype(F), (py * r).astype(F), (pz * r).astype(F)
+
+
+def kitti_scene(seed=42, ground=50_000, per_obstacle=2_000, outliers=1_000):
+    """tests/real_world_pipeline.rs:19-55: ground plane + 3 box obstacles + scattered outliers."""
+    parts = []
+    parts.append((uniform(seed, ground, -20, 20, 0), uniform(seed, ground, -20, 20, 1),
+                  uniform(seed, ground, -0.05, 0.05, 2)))
+    centers = [(5.0, 3.0, 1.0), (-8.0, -5.0, 0.8), (12.0, -10.0, 1.5)]
+    for i, c in enumerate(centers):
+        s = 3 + 3 * i
+        parts.append((F(c[0]) + uniform(seed, per_obstacle, -0.8, 0.8, s),
+                      F(c[1]) + uniform(seed, per_obstacle, -0.8, 0.8, s + 1),
+                      F(c[2]) + uniform(seed, per_obstacle, -0.5, 0.5, s + 2)))
+    parts.append((uniform(seed, outliers, -30, 30, 20), uniform(seed, outliers, -30, 30, 21),
+                  uniform(seed, outliers, -5, 10, 22)))
+    return tuple(np.concatenate([p[a] for p in parts]).astype(F) for a in range(3))
+
+
+def rot_z(angle):
+    a = F(angle)
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=F)
+
+
+def degenerate_cloud(n=300, seed=7):
+    """Duplicates, a lattice full of distance ties, co-planar points and non-finite rows."""
+    x, y, z = uniform_cloud(n, seed, 0.0, 4.0)
+    x, y, z = x.copy(), y.copy(), z.copy()
+    # exact duplicates
+    x[10:20], y[10:20], z[10:20] = x[0:10], y[0:10], z[0:10]
+    # integer lattice block (many equidistant neighbours)
+    g = np.array([(i, j, k) for i in range(4) for j in range(4) for k in range(4)], dtype=F)
+    x[40:104], y[40:104], z[40:104] = g[:, 0], g[:, 1], g[:, 2]
+    # co-planar patch (would overflow a kiddo bucket on one axis)
+    z[120:200] = F(2.5)
+    # non-finite rows
+    x[5] = np.nan
+    y[25] = np.inf
+    z[33] = -np.inf
+    return x, y, z

@@ -1,0 +1,278 @@
+"""GPU parity: libpcrs_hip.so (through the C-ABI) against the CPU oracle on the same seeded
+inputs.  Bit-exact for neighbour indices, squared/Euclidean distances, SOR means, thresholds and
+masks; 1e-5 for normals (f64 acos/cos differ between the device and host math libraries)."""
+import numpy as np
+import pytest
+
+import gen
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+NO = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pointclouds_rs import hip as h
+
+    return h
+
+
+def clouds():
+    return {
+        "uniform3k": gen.uniform_cloud(3000, 42),
+        "hemisphere2k": gen.hemisphere(2000, 99, 5.0),
+        "kitti": gen.kitti_scene(42, 4000, 300, 100),
+        "degenerate": gen.degenerate_cloud(300, 7),
+        "tiny": gen.uniform_cloud(5, 3),
+    }
+
+
+ALGOS = [1, 2]  # PCRS_ALGO_BRUTE, PCRS_ALGO_GRID
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=["brute", "grid"])
+@pytest.mark.parametrize("name", list(clouds()))
+@pytest.mark.parametrize("k", [1, 4, 10, 17, 33, 70, 200])
+def test_knn_self_bit_exact(hip, oracle, name, k, algo):
+    x, y, z = clouds()[name]
+    ix = hip.Index(x, y, z, k_hint=k, algo=algo)
+    idx, dist, cnt = ix.knn(x, y, z, k)
+    ix.close()
+    ridx, rdist, _, rcnt = oracle.knn(x, y, z, x, y, z, k, algo=1)
+    assert np.array_equal(cnt, rcnt)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=["brute", "grid"])
+def test_knn_external_queries(hip, oracle, algo):
+    x, y, z = gen.uniform_cloud(6000, 5, 0, 10)
+    qx, qy, qz = gen.uniform_cloud(1500, 6, -5, 15)  # many queries outside the cloud's box
+    qx = qx.copy()
+    qx[7] = np.nan
+    qy[11] = np.inf
+    for k in (1, 3, 16):
+        ix = hip.Index(x, y, z, k_hint=k, algo=algo)
+        idx, dist, cnt = ix.knn(qx, qy, qz, k)
+        ix.close()
+        ridx, rdist, _, rcnt = oracle.knn(x, y, z, qx, qy, qz, k, algo=1)
+        assert np.array_equal(cnt, rcnt) and cnt[7] == 0 and cnt[11] == 0
+        assert np.array_equal(idx, ridx)
+        assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,k", [(20000, 10), (50000, 16)])
+def test_sor_parity_mid_size(hip, oracle, n, k):
+    x, y, z = gen.uniform_cloud(n, 42)
+    keep, n_keep, thr, mean = hip.sor(x, y, z, k, 1.0)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, k, 1.0, algo=1)
+    assert np.array_equal(mean.view(np.uint32), rmean.view(np.uint32))
+    assert F(thr).view(np.uint32) == F(rthr).view(np.uint32)
+    assert n_keep == rn and np.array_equal(keep, rkeep)
+    assert 0 < n_keep < n
+
+
+@pytest.mark.parametrize("name", ["degenerate", "kitti", "tiny", "hemisphere2k"])
+def test_sor_parity_irregular(hip, oracle, name):
+    x, y, z = clouds()[name]
+    for k, mul in ((1, 0.0), (8, 1.0), (20, 2.0), (400, 1.0)):
+        keep, n_keep, thr, mean = hip.sor(x, y, z, k, mul)
+        rkeep, rn, rthr, rmean = oracle.sor(x, y, z, k, mul, algo=0)
+        assert np.array_equal(mean.view(np.uint32), rmean.view(np.uint32)), (name, k)
+        assert np.array_equal(keep, rkeep) and n_keep == rn
+        assert F(thr).view(np.uint32) == F(rthr).view(np.uint32)
+
+
+def test_sor_edge_cases(hip):
+    e = np.empty(0, dtype=F)
+    keep, n_keep, thr, _ = hip.sor(e, e, e, 5, 1.0)
+    assert len(keep) == 0 and n_keep == 0
+    keep, n_keep, _, _ = hip.sor([1], [2], [3], 5, 1.0)  # statistical_outlier.rs:10-12
+    assert list(keep) == [True] and n_keep == 1
+    keep, n_keep, _, _ = hip.sor([1, 2], [3, 4], [5, 6], 0, 1.0)  # :5-7
+    assert not keep.any() and n_keep == 0
+    nan = float("nan")
+    keep, n_keep, thr, mean = hip.sor([nan, nan], [0, 0], [0, 0], 3, 1.0)  # :49-51
+    assert not keep.any() and np.isnan(thr) and np.all(np.isinf(mean))
+    # one finite point among non-finite ones: its only neighbour is itself, mean 0
+    keep, n_keep, thr, mean = hip.sor([1, nan, nan], [1, 0, 0], [1, 0, 0], 3, 1.0)
+    assert list(keep) == [True, False, False] and mean[0] == 0.0
+
+
+def normals_close(got, ref, tol):
+    g = np.stack(got, 1).astype(np.float64)
+    r = np.stack(ref, 1).astype(np.float64)
+    return np.abs(g - r).max(axis=1) <= tol
+
+
+@pytest.mark.parametrize("name,k", [("uniform3k", 16), ("hemisphere2k", 15), ("kitti", 10),
+                                    ("degenerate", 8), ("tiny", 3), ("uniform3k", 100)])
+def test_normals_parity(hip, oracle, name, k):
+    x, y, z = clouds()[name]
+    vp = (0.5, -1.0, 30.0)
+    got = hip.normals(x, y, z, k, vp)
+    ref = oracle.normals(x, y, z, k, vp, algo=0)
+    ok = normals_close(got, ref, 1e-5)
+    exact = np.all(np.stack(got, 1).view(np.uint32) == np.stack(ref, 1).view(np.uint32), axis=1)
+    # A flipped sign is legitimate only where n . (viewpoint - p) rounds to zero.
+    bad = np.nonzero(~ok)[0]
+    for i in bad:
+        flipped = normals_close(tuple(-c[i:i + 1] for c in got), tuple(c[i:i + 1] for c in ref), 1e-5)[0]
+        v = np.array(vp) - np.array([x[i], y[i], z[i]], dtype=np.float64)
+        dot = abs(float(np.dot([c[i] for c in ref], v)))
+        assert flipped and dot < 1e-4 * np.linalg.norm(v), (name, i, [c[i] for c in got], [c[i] for c in ref])
+    assert exact.mean() > 0.95, f"only {exact.mean():.3f} bit-exact"
+
+
+def test_normals_50k_parity(hip, oracle):
+    x, y, z = gen.uniform_cloud(50000, 42)
+    got = hip.normals(x, y, z, 16)
+    ref = oracle.normals(x, y, z, 16, algo=1)
+    ok = normals_close(got, ref, 1e-5)
+    assert ok.mean() > 0.9999, ok.mean()
+
+
+def test_sor_normals_fused_matches_separate(hip):
+    x, y, z = gen.uniform_cloud(20000, 8)
+    keep, n_keep, thr, nrm = hip.sor_normals(x, y, z, 16, 1.0, 16)
+    keep2, n_keep2, thr2, _ = hip.sor(x, y, z, 16, 1.0)
+    nrm2 = hip.normals(x, y, z, 16)
+    assert np.array_equal(keep, keep2) and n_keep == n_keep2 and thr == thr2
+    for a, b in zip(nrm, nrm2):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_radius_count_parity(hip, oracle):
+    x, y, z = gen.degenerate_cloud(400, 2)
+    ix = hip.Index(x, y, z)
+    for r in (0.3, 1.0, 2.5):
+        c = ix.radius_count(x, y, z, r)
+        _, _, rc = oracle.radius_outlier(x, y, z, r, 1)
+        assert np.array_equal(c, rc)
+    assert not ix.radius_count(x, y, z, -1.0).any()
+    assert not ix.radius_count(x, y, z, float("nan")).any()
+    ix.close()
+
+
+def test_apply_transform_bit_exact(hip, oracle):
+    x, y, z = gen.uniform_cloud(10000, 4, -50, 50)
+    R = gen.rot_z(0.3)
+    t = (0.25, -3.0, 7.5)
+    got = hip.apply_transform(x, y, z, R, t)
+    ref = oracle.apply_transform(x, y, z, R, t)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    r1, t1 = hip.compose(R, t, gen.rot_z(-0.1), (1, 2, 3))
+    r2, t2 = oracle.compose(R, t, gen.rot_z(-0.1), (1, 2, 3))
+    assert np.array_equal(r1, r2) and np.array_equal(t1, t2)
+
+
+def _icp_pair(n, seed=99):
+    tgt = gen.hemisphere(n, seed, 5.0)
+    return tgt
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=["brute", "grid"])
+def test_correspondences_and_step_sums(hip, oracle, algo):
+    from pointclouds_rs import _ffi
+
+    tgt = _icp_pair(5000)
+    tn = oracle.normals(*tgt, 16, algo=1)
+    src = oracle.apply_transform(*tgt, gen.rot_z(0.05), (0.3, -0.2, 0.1))
+    ix = hip.Index(*tgt, k_hint=1, algo=algo)
+    for max_d in (np.inf, 0.25):
+        t, d, n = ix.find_correspondences(*src, max_d)
+        rt, rd, rn = oracle.find_correspondences(*src, *tgt, max_d, algo=1)
+        assert n == rn and np.array_equal(t, rt)
+        assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+    ix.close()
+    icp = hip.Icp(src, tgt, tn)
+    for max_d in (np.inf, 0.25):
+        ref = oracle.icp_step(src, tgt, tn, max_d, algo=1)
+        s = icp.accumulate(_ffi.ICP_POINT_TO_PLANE, max_d)
+        assert s[0] == ref["n_corr"]
+        assert np.isclose(s[1], ref["sum_d2"], rtol=1e-12)
+        ata = ref["plane"][:36].reshape(6, 6)
+        tri = [ata[r, c] for r in range(6) for c in range(r, 6)]
+        assert np.allclose(s[2:23], tri, rtol=1e-11, atol=1e-12)
+        assert np.allclose(s[23:29], ref["plane"][36:], rtol=1e-11, atol=1e-12)
+        p = icp.accumulate(_ffi.ICP_POINT_TO_POINT, max_d)
+        assert p[0] == ref["n_corr"]
+        assert np.allclose(p[2:17], ref["point"], rtol=1e-11, atol=1e-12)
+        # rmse from the f64 sum vs the reference's sequential f32 sum: within 1e-5 relative
+        assert abs(np.sqrt(s[1] / s[0]) - ref["rmse"]) <= 1e-5 * ref["rmse"]
+    icp.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["point", "plane"])
+def test_icp_run_matches_oracle(hip, oracle, mode):
+    tgt = _icp_pair(4000)
+    tn = oracle.normals(*tgt, 16, algo=1)
+    src = oracle.apply_transform(*tgt, gen.rot_z(0.05), (0.3, -0.2, 0.1))
+    # tolerance 0 never fires (|d rmse| < 0 is false): all iterations run, as in the benchmark
+    res = hip.icp_register(mode, src, tgt, tn, 30, 0.0, np.inf)
+    rc, ref, _ = oracle.icp(mode, src, tgt, tn, max_iter=30, tol=0.0, algo=1)
+    assert rc == 0 and res.num_iterations == ref.num_iterations == 30
+    assert not res.converged and not ref.converged
+    assert abs(res.fitness - ref.fitness) == 0
+    assert abs(res.rmse - ref.rmse) <= 1e-5 * max(ref.rmse, 1e-3)
+    assert np.allclose(np.array(res.rotation), np.array(ref.rot), atol=2e-5)
+    assert np.allclose(np.array(res.translation), np.array(ref.t), atol=5e-5)
+    # and the registration actually recovers the inverse motion
+    assert np.allclose(np.array(res.rotation).reshape(3, 3), gen.rot_z(-0.05), atol=2e-2)
+
+
+def test_icp_with_tolerance_and_gate(hip, oracle):
+    tgt = _icp_pair(3000)
+    tn = oracle.normals(*tgt, 16, algo=1)
+    src = oracle.apply_transform(*tgt, gen.rot_z(0.03), (0.1, 0.05, -0.05))
+    for mode in (0, 1):
+        res = hip.icp_register(mode, src, tgt, tn, 50, 1e-5, 1.0)
+        rc, ref, _ = oracle.icp(mode, src, tgt, tn, max_iter=50, tol=1e-5, max_d=1.0, algo=1)
+        assert bool(res.converged) == bool(ref.converged)
+        assert abs(int(res.num_iterations) - int(ref.num_iterations)) <= 1
+        assert abs(res.rmse - ref.rmse) <= 1e-4 * max(ref.rmse, 1e-3)
+    # max_iterations == 0: one metrics pass (icp.rs:190-197)
+    res = hip.icp_register(0, src, tgt, None, 0, 1e-5, np.inf)
+    rc, ref, _ = oracle.icp(0, src, tgt, None, max_iter=0, tol=1e-5, algo=1)
+    assert res.num_iterations == 0 and res.fitness == ref.fitness
+    assert abs(res.rmse - ref.rmse) <= 1e-5 * ref.rmse
+
+
+def test_kitti_scene_sor(hip, oracle):
+    """tests/real_world_pipeline.rs:106-113 on the raw 57k-point scene: removes some, keeps most."""
+    x, y, z = gen.kitti_scene(42)
+    keep, n_keep, thr, mean = hip.sor(x, y, z, 20, 2.0)
+    assert len(x) // 2 < n_keep < len(x)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, 20, 2.0, algo=1)
+    assert np.array_equal(mean.view(np.uint32), rmean.view(np.uint32))
+    assert np.array_equal(keep, rkeep)
+
+
+def test_python_surface_end_to_end(hip):
+    """tests/test_python.py:98-173 of the reference, through the pointclouds_rs mirror."""
+    import pointclouds_rs as pc
+
+    rng = np.random.default_rng(0)
+    cluster = (rng.random((50, 3)) * 0.1).astype(F)
+    data = np.vstack([cluster, np.array([[100.0, 100.0, 100.0]], dtype=F)])
+    cloud = pc.PointCloud.from_numpy(data)
+    assert pc.statistical_outlier_removal(cloud, 10, 1.0).len() <= cloud.len()
+    assert pc.radius_outlier_removal(cloud, 0.5, 3).len() < cloud.len()
+    xs = np.linspace(-2, 2, 10, dtype=F)
+    xx, yy = np.meshgrid(xs, xs)
+    zz = np.random.default_rng(123).normal(0, 1e-4, 100).astype(F)
+    tdata = np.column_stack([xx.ravel(), yy.ravel(), zz]).astype(F)
+    target = pc.estimate_normals(pc.PointCloud.from_numpy(tdata), 10)
+    assert target.len() == 100 and target.normals_numpy().shape == (100, 3)
+    sdata = tdata.copy()
+    sdata[:, 2] += 0.3
+    res = pc.icp_point_to_plane(pc.PointCloud.from_numpy(sdata), target)
+    assert res.converged and res.rmse < 0.1
+    sq = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], dtype=F)
+    res = pc.icp_point_to_point(pc.PointCloud.from_numpy(sq),
+                                pc.PointCloud.from_numpy(sq + np.array([0.1, 0, 0], dtype=F)))
+    assert res.converged and res.rmse < 0.1
+    moved = pc.apply_transform(pc.PointCloud.from_numpy(sq), np.eye(3), [1, 2, 3])
+    assert np.array_equal(moved.to_numpy(), sq + np.array([1, 2, 3], dtype=F))

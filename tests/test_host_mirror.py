@@ -1,0 +1,52 @@
+"""Host-side mirror of the PyO3 surface: argument validation and cloud bookkeeping
+(tests/test_python.py of the reference, the parts that need no device)."""
+import numpy as np
+import pytest
+
+import pointclouds_rs as pc
+
+
+def test_from_numpy_roundtrip_and_types():
+    a = np.arange(12, dtype=np.float32).reshape(4, 3)
+    c = pc.PointCloud.from_numpy(a)
+    assert c.len() == 4 and len(c) == 4 and not c.is_empty()
+    assert np.array_equal(c.to_numpy(), a)
+    assert repr(c) == "PointCloud(n=4)"
+    c64 = pc.PointCloud.from_numpy(a.astype(np.float64))
+    assert c64.to_numpy().dtype == np.float32
+    with pytest.raises(TypeError):
+        pc.PointCloud.from_numpy(a.astype(np.int32))
+    with pytest.raises(ValueError):
+        pc.PointCloud.from_numpy(np.asfortranarray(a))
+    with pytest.raises(ValueError):
+        pc.PointCloud.from_numpy(np.zeros((4, 2), dtype=np.float32))
+
+
+def test_select_and_inverse():
+    a = np.arange(15, dtype=np.float32).reshape(5, 3)
+    c = pc.PointCloud.from_numpy(a)
+    assert np.array_equal(c.select([3, 1]).to_numpy(), a[[3, 1]])
+    assert np.array_equal(c.select_inverse([0, 4]).to_numpy(), a[[1, 2, 3]])
+    with pytest.raises(IndexError):
+        c.select([5])
+    with pytest.raises(IndexError):
+        c.select_inverse([7])
+
+
+def test_argument_validation_matches_reference():
+    c = pc.PointCloud.from_numpy(np.zeros((2, 3), dtype=np.float32))
+    for bad in (float("nan"), float("inf"), -1.0):
+        with pytest.raises(ValueError):
+            pc.statistical_outlier_removal(c, 5, bad)  # crates/python/src/filters.rs:42-46
+    for bad in (0.0, -1.0, float("inf"), float("nan")):
+        with pytest.raises(ValueError):
+            pc.radius_outlier_removal(c, bad, 3)  # filters.rs:57-61
+    with pytest.raises(ValueError):
+        pc.icp_point_to_plane(c, c)  # registration.rs:67-72: target has no normals
+    with pytest.raises(TypeError):
+        pc.statistical_outlier_removal(np.zeros((2, 3)), 5, 1.0)
+
+
+def test_out_of_scope_functions_are_absent():
+    for name in ("voxel_downsample", "passthrough_filter", "ransac_plane", "euclidean_cluster"):
+        assert not hasattr(pc, name)

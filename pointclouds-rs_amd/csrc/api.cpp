@@ -76,12 +76,6 @@ void pcrs_timing_end(pcrs_ctx *ctx) {
 
 namespace {
 
-#define PCRS_TRY(expr)                \
-    do {                              \
-        int _rc = (expr);             \
-        if (_rc != PCRS_OK) return _rc; \
-    } while (0)
-
 int bind_device(pcrs_ctx *ctx) {
     if (!ctx) return PCRS_ERR_INVALID_ARG;
     PCRS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -101,6 +95,7 @@ int download(pcrs_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int run_query(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed) {
     ix->stats[0] = ix->stats[1] = ix->stats[2] = 0;
+    ix->stats_dev = nullptr;
     if (ix->algo == PCRS_ALGO_GRID) return pcrs_launch_knn_grid(ix, q, out, kneed);
     ix->stats[2] = q.nq;
     return pcrs_launch_knn_bf(ix->ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, nullptr, nullptr,
@@ -275,6 +270,19 @@ size_t pcrs_index_len(const pcrs_index *index) { return index ? index->m : 0; }
 
 int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]) {
     if (!index || !stats) return PCRS_ERR_INVALID_ARG;
+    if (index->stats_dev) {
+        pcrs_ctx *ctx = index->ctx;
+        uint32_t c[3] = {0, 0, 0};
+        if (hipSetDevice(ctx->device) != hipSuccess ||
+            hipMemcpyAsync(c, index->stats_dev, sizeof(c), hipMemcpyDeviceToHost, ctx->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return PCRS_ERR_HIP;
+        stats[0] = index->stats_nq - c[0];  // certified by the 27-cell cube
+        stats[1] = c[0] - c[2];             // certified by a larger cube
+        stats[2] = c[2];                    // brute force
+        return PCRS_OK;
+    }
     for (int i = 0; i < 3; ++i) stats[i] = index->stats[i];
     return PCRS_OK;
 }
@@ -561,7 +569,12 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
 
 int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n, uint32_t k,
              float std_mul, uint8_t *keep, size_t *n_keep, float *thr_out, float *mean_out) {
-    if (!keep) return PCRS_ERR_INVALID_ARG;
+    if (!keep && n) return PCRS_ERR_INVALID_ARG;
+    if (n == 0) {
+        if (n_keep) *n_keep = 0;
+        if (thr_out) *thr_out = std::numeric_limits<float>::quiet_NaN();
+        return bind_device(ctx);
+    }
     if (!mean_out)
         return pcrs_sor_normals(ctx, x, y, z, n, k, std_mul, 0, nullptr, keep, n_keep, thr_out,
                                 nullptr, nullptr, nullptr);

@@ -1,6 +1,784 @@
-// placeholder until the grid kernels land
+// Uniform-grid pruned exact k-nearest-neighbour search for gfx950.
+//
+// Build: the finite points are counting-sorted by cell (x-fastest cell order) into one AoS
+// float4 array (x, y, z, original index), so the cells of one grid row are contiguous and a
+// (2R+1)-cell row of a query's neighbourhood is a single slot range.
+//
+// Query: one query per lane.  Self queries run in sorted-slot order, so the 64 lanes of a wave
+// sit in the same or adjacent cells and their candidate loads hit the same cache lines.  A lane
+// walks the (2R+1)^3 cube of cells around its own cell:
+//   pass 1  keeps the K smallest squared distances in registers with a branch-free
+//           v_med3_f32 chain (no indices, no divergence); this already yields the SOR mean.
+//   check   the result is exact iff the K-th distance is smaller than the distance from the
+//           query to the nearest face of the cube that is not a grid boundary.
+//   pass 2  (only when neighbour identities are needed) walks the cube again, appends the slots
+//           with d2 <= K-th distance to a per-lane LDS list, then orders those few candidates by
+//           the full (d2, index) key in registers and runs the fused consumer.
+// Queries that cannot be certified go to a compact list and are retried with a larger cube,
+// and finally by the brute-force kernel, so the result is exact for every input.
+#include <cstdlib>
+
 #include "knn_common.h"
-int pcrs_grid_build(pcrs_index *ix, uint32_t) { ix->algo = PCRS_ALGO_BRUTE; return PCRS_OK; }
-int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &, const KnnOut &, uint32_t) {
-    return pcrs_set_err(ix->ctx, PCRS_ERR_INVALID_ARG, "grid search not built");
+
+#pragma clang fp contract(off)
+
+namespace pcrs {
+
+constexpr int GB_THREADS = 256;
+
+// ----------------------------------------------------------------------------- build kernels
+
+struct BBoxPartial {
+    float lo[3], hi[3];
+    unsigned long long nvalid;
+};
+
+__global__ __launch_bounds__(GB_THREADS) void bbox_kernel(const float *x, const float *y,
+                                                          const float *z, uint32_t m,
+                                                          BBoxPartial *partials) {
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    unsigned nv = 0;
+    for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < m; i += gridDim.x * GB_THREADS) {
+        const float p[3] = {x[i], y[i], z[i]};
+        if (finite3(p[0], p[1], p[2])) {
+            ++nv;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], p[a]);
+                hi[a] = fmaxf(hi[a], p[a]);
+            }
+        }
+    }
+    __shared__ float slo[3][GB_THREADS / 64], shi[3][GB_THREADS / 64];
+    __shared__ unsigned snv[GB_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+        }
+        if (lane == 0) {
+            slo[a][wave] = lo[a];
+            shi[a][wave] = hi[a];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) nv += __shfl_down(nv, off, 64);
+    if (lane == 0) snv[wave] = nv;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BBoxPartial p;
+        p.nvalid = 0;
+        for (int a = 0; a < 3; ++a) {
+            p.lo[a] = __builtin_inff();
+            p.hi[a] = -__builtin_inff();
+        }
+        for (int w = 0; w < GB_THREADS / 64; ++w) {
+            for (int a = 0; a < 3; ++a) {
+                p.lo[a] = fminf(p.lo[a], slo[a][w]);
+                p.hi[a] = fmaxf(p.hi[a], shi[a][w]);
+            }
+            p.nvalid += snv[w];
+        }
+        partials[blockIdx.x] = p;
+    }
+}
+
+__device__ __forceinline__ int cell_coord(float p, float o, float inv, int n) {
+    float f = floorf((p - o) * inv);
+    f = fminf(fmaxf(f, 0.0f), (float)(n - 1));
+    return (int)f;
+}
+
+__device__ __forceinline__ uint32_t cell_index(const GridGeom &g, float x, float y, float z) {
+    const int cx = cell_coord(x, g.ox, g.inv, g.nx);
+    const int cy = cell_coord(y, g.oy, g.inv, g.ny);
+    const int cz = cell_coord(z, g.oz, g.inv, g.nz);
+    return ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+}
+
+// cell id per point (PCRS_NO_INDEX for non-finite points) and the cell histogram
+__global__ __launch_bounds__(GB_THREADS) void cell_count_kernel(const float *x, const float *y,
+                                                                const float *z, uint32_t m,
+                                                                GridGeom g, uint32_t *cell_id,
+                                                                uint32_t *counts) {
+    for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < m; i += gridDim.x * GB_THREADS) {
+        const float px = x[i], py = y[i], pz = z[i];
+        uint32_t c = PCRS_NO_INDEX;
+        if (finite3(px, py, pz)) {
+            c = cell_index(g, px, py, pz);
+            atomicAdd(&counts[c], 1u);
+        }
+        if (cell_id) cell_id[i] = c;
+    }
+}
+
+__global__ __launch_bounds__(GB_THREADS) void nonempty_kernel(const uint32_t *counts,
+                                                              uint32_t ncell, uint32_t *out) {
+    unsigned local = 0;
+    for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < ncell;
+         i += gridDim.x * GB_THREADS)
+        local += counts[i] ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
+// Exclusive scan of counts[0..n) in three launches: per-block scan of 1024 elements, scan of the
+// block totals, add-back.  counts[n] receives the grand total.
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_BLOCK = GB_THREADS * SCAN_ITEMS;
+
+__global__ __launch_bounds__(GB_THREADS) void scan_block_kernel(uint32_t *data, uint32_t n,
+                                                                uint32_t *block_sums) {
+    __shared__ uint32_t wsum[GB_THREADS / 64];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], t = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? data[base + i] : 0u;
+        t += v[i];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = t;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wsum[w];
+    uint32_t run = wave_off + incl - t;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) data[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == GB_THREADS - 1) block_sums[blockIdx.x] = wave_off + incl;
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *block_sums, uint32_t nblocks,
+                                                         uint32_t *total_out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
+        uint32_t incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += wsum[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(GB_THREADS) void scan_add_kernel(uint32_t *data, uint32_t n,
+                                                              const uint32_t *block_sums) {
+    const uint32_t off = block_sums[blockIdx.x];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) data[base + i] += off;
+}
+
+// counting-sort scatter: fill[] starts as a copy of cell_start and is advanced atomically
+__global__ __launch_bounds__(GB_THREADS) void scatter_kernel(const float *x, const float *y,
+                                                             const float *z, uint32_t m,
+                                                             const uint32_t *cell_id,
+                                                             uint32_t *fill, float4 *spts) {
+    for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < m; i += gridDim.x * GB_THREADS) {
+        const uint32_t c = cell_id[i];
+        if (c == PCRS_NO_INDEX) continue;
+        const uint32_t s = atomicAdd(&fill[c], 1u);
+        spts[s] = make_float4(x[i], y[i], z[i], __uint_as_float(i));
+    }
+}
+
+// ----------------------------------------------------------------------------- query kernel
+
+struct CellArgs {
+    GridGeom g;
+    const uint32_t *cell_start;
+    const float4 *spts;
+    uint32_t nvalid;
+    const float *rx, *ry, *rz;  // original columns (consumer gathers)
+    // query addressing:
+    //   qmode 0: position p is sorted slot p (p < nq); query = spts[p], output slot = idx - q_begin
+    //   qmode 1: position p is query p of (qx, qy, qz)
+    //   qmode 2: query qlist[p] of (qx, qy, qz), p < *qcount
+    //   qmode 3: sorted slot qlist[p], p < *qcount (self queries of a sub-range, compacted)
+    int qmode;
+    const float *qx, *qy, *qz;
+    uint32_t nq;
+    uint32_t q_begin, q_len;
+    const uint32_t *qlist;
+    const uint32_t *qcount;
+    int R;                  // cube half-width in cells
+    uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
+    uint32_t *fail_count;
+    uint32_t kcert;         // neighbours that must be certified (<= K)
+    uint32_t kcollect;      // neighbours whose identity is needed (pass 2), 0 = none
+};
+
+// Calls f(point, slot) for every point of the (2R+1)^3 cube of cells centred on (cx, cy, cz).
+template <class F>
+__device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int cz, F f) {
+    const GridGeom &g = a.g;
+    const int R = a.R;
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+    for (int dz = -R; dz <= R; ++dz) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= g.nz) continue;
+        for (int dy = -R; dy <= R; ++dy) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= g.ny) continue;
+            const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+            const uint32_t s0 = a.cell_start[row + x0];
+            const uint32_t s1 = a.cell_start[row + x1 + 1];
+            for (uint32_t s = s0; s < s1; ++s) f(a.spts[s], s);
+        }
+    }
+}
+
+template <int K, bool COLLECT>
+__global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut out) {
+    constexpr int CAP = K + 7;  // per-lane candidate list for pass 2
+    __shared__ uint32_t lst[COLLECT ? CAP : 1][GB_THREADS];
+
+    uint32_t total = a.nq;
+    if (a.qmode >= 2) total = *a.qcount;
+    const GridGeom &g = a.g;
+
+    for (uint32_t pos = blockIdx.x * GB_THREADS + threadIdx.x; pos < total;
+         pos += gridDim.x * GB_THREADS) {
+        uint32_t qi;
+        float qx, qy, qz;
+        if (a.qmode == 0 || a.qmode == 3) {
+            const float4 p = a.spts[a.qmode == 3 ? a.qlist[pos] : pos];
+            const uint32_t orig = __float_as_uint(p.w);
+            if (orig - a.q_begin >= a.q_len) continue;  // not a query of this call
+            qi = orig - a.q_begin;
+            qx = p.x;
+            qy = p.y;
+            qz = p.z;
+        } else {
+            qi = (a.qmode == 2) ? a.qlist[pos] : pos;
+            qx = a.qx[qi];
+            qy = a.qy[qi];
+            qz = a.qz[qi];
+        }
+        const bool qvalid = finite3(qx, qy, qz);
+        if (!qvalid) {  // no neighbours: the consumers write their defaults
+            uint64_t none[1] = {PCRS_EMPTY_KEY};
+            consume(RegNbrs<1>(none), 0u, false, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, out);
+            continue;
+        }
+        const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+        const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
+        const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
+        const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+
+        // ---- pass 1: K smallest squared distances, ascending, branch-free
+        float D[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
+        walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t) {
+            const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+#pragma unroll
+            for (int s = K - 1; s > 0; --s) D[s] = __builtin_amdgcn_fmed3f(d2, D[s - 1], D[s]);
+            D[0] = fminf(D[0], d2);
+        });
+
+        // ---- certification: every point outside the cube is farther than `margin`
+        const int R = a.R;
+        const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
+                           (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
+        bool certified = whole;
+        float tau_cert = __builtin_inff();
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if ((uint32_t)i == a.kcert - 1) tau_cert = D[i];
+        if (!whole) {
+            float margin = __builtin_inff();
+            const float u[3] = {ux, uy, uz};
+            const int c[3] = {cx, cy, cz};
+            const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                if (c[ax] + R < n[ax] - 1)
+                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+            }
+            // slack covers the f32 rounding of the cell assignment and of the offsets above
+            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
+            certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
+        }
+        if (!certified) {
+            if (a.fail_list) {
+                const uint32_t f = atomicAdd(a.fail_count, 1u);
+                a.fail_list[f] = qi;
+            }
+            continue;
+        }
+
+        // ---- SOR mean straight from the sorted distances (statistical_outlier.rs:28-37)
+        if (out.mean) {
+            const uint32_t kk = out.k_sor + 1u;
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) c += ((uint32_t)i < kk && D[i] < __builtin_inff()) ? 1u : 0u;
+            const uint32_t first = c > 1u ? 1u : 0u;
+            float mean = __builtin_inff();
+            if (c - first > 0u) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < K; ++i)
+                    if ((uint32_t)i >= first && (uint32_t)i < c) sum += sqrtf(D[i]);
+                mean = sum / (float)(c - first);
+            }
+            out.mean[qi] = mean;
+        }
+
+        if constexpr (COLLECT) {
+            // ---- pass 2: identities of the kcollect nearest
+            float tau = __builtin_inff();
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                if ((uint32_t)i == a.kcollect - 1) tau = D[i];
+            uint32_t cnt = 0;
+            walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t s) {
+                const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+                if (d2 <= tau) {
+                    if (cnt < (uint32_t)CAP) lst[cnt][threadIdx.x] = s;
+                    ++cnt;
+                }
+            });
+            if (cnt > (uint32_t)CAP) {  // too many ties at the K-th distance for the list
+                if (a.fail_list) {
+                    const uint32_t f = atomicAdd(a.fail_count, 1u);
+                    a.fail_list[f] = qi;
+                }
+                continue;
+            }
+            TopK<K> top;
+            top.init(true);
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float4 p = a.spts[lst[j][threadIdx.x]];
+                top.offer(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+            }
+            KnnOut o2 = out;
+            o2.mean = nullptr;  // already written from D[]
+            uint32_t have = top.count();
+            if (have > a.kcollect) have = a.kcollect;
+            consume(RegNbrs<K>(top.key), have, true, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, o2);
+        }
+    }
+}
+
+// Sorted slots whose original index lies in [q_begin, q_begin + q_len), in (approximately)
+// slot order, so that a sub-range of a cloud is still processed with full waves.
+__global__ __launch_bounds__(GB_THREADS) void owned_slots_kernel(const float4 *spts,
+                                                                 uint32_t nvalid, uint32_t q_begin,
+                                                                 uint32_t q_len, uint32_t *list,
+                                                                 uint32_t *count) {
+    const uint32_t s = blockIdx.x * GB_THREADS + threadIdx.x;
+    bool own = false;
+    if (s < nvalid) own = (__float_as_uint(spts[s].w) - q_begin) < q_len;
+    // one atomic per wave keeps the lanes of a wave contiguous in the list
+    const unsigned long long mask = __ballot(own);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && mask) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (own) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = s;
+}
+
+// 1-NN variant: a single pass tracking the best (d2, index) key.
+__global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut out) {
+    uint32_t total = a.nq;
+    if (a.qmode == 2) total = *a.qcount;
+    const GridGeom &g = a.g;
+    for (uint32_t pos = blockIdx.x * GB_THREADS + threadIdx.x; pos < total;
+         pos += gridDim.x * GB_THREADS) {
+        const uint32_t qi = (a.qmode == 2) ? a.qlist[pos] : pos;
+        const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];
+        if (!finite3(qx, qy, qz)) {
+            out.nn_idx[qi] = PCRS_NO_INDEX;
+            if (out.nn_d2) out.nn_d2[qi] = __builtin_inff();
+            continue;
+        }
+        const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+        const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
+        const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
+        const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+        uint64_t best = PCRS_EMPTY_KEY;
+        float best_d2 = __builtin_inff();
+        walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t) {
+            const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+            if (d2 <= best_d2) {
+                const uint64_t k = make_key(d2, __float_as_uint(p.w));
+                if (k < best) {
+                    best = k;
+                    best_d2 = d2;
+                }
+            }
+        });
+        const int R = a.R;
+        const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
+                           (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
+        bool certified = whole;
+        if (!whole) {
+            float margin = __builtin_inff();
+            const float u[3] = {ux, uy, uz};
+            const int c[3] = {cx, cy, cz};
+            const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                if (c[ax] + R < n[ax] - 1)
+                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+            }
+            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
+            certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f));
+        }
+        if (!certified) {
+            if (a.fail_list) {
+                const uint32_t f = atomicAdd(a.fail_count, 1u);
+                a.fail_list[f] = qi;
+            }
+            continue;
+        }
+        out.nn_idx[qi] = (best == PCRS_EMPTY_KEY) ? PCRS_NO_INDEX : key_idx(best);
+        if (out.nn_d2) out.nn_d2[qi] = best_d2;
+    }
+}
+
+}  // namespace pcrs
+
+using namespace pcrs;
+
+// ----------------------------------------------------------------------------- host: build
+
+namespace {
+
+unsigned grid_for(pcrs_ctx *ctx, size_t n, int threads) {
+    size_t blocks = (n + threads - 1) / threads;
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+int exclusive_scan(pcrs_ctx *ctx, uint32_t *data, uint32_t n, DevBuf &sums) {
+    const uint32_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    PCRS_HIP_CHECK(ctx, sums.alloc(((size_t)nblocks + 1) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream, data, n,
+                       sums.as<uint32_t>());
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums.as<uint32_t>(),
+                       nblocks, data + n);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream, data, n,
+                       sums.as<uint32_t>());
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// Points per cell the grid aims for: the 27-cell cube then holds ~27 P candidates and the ball
+// of radius one cell ~4.2 P >= 2 K points, so the first stage certifies almost every query.
+double target_occupancy(uint32_t k_hint) {
+    // experiments only: PCRS_GRID_OCC overrides the points-per-cell target
+    if (const char *e = getenv("PCRS_GRID_OCC")) {
+        const double v = atof(e);
+        if (v >= 0.5 && v <= 256.0) return v;
+    }
+    double p = 0.5 * (double)(k_hint ? k_hint : 16);
+    if (p < 2.0) p = 2.0;
+    if (p > 64.0) p = 64.0;
+    return p;
+}
+
+constexpr double kMaxDim = 1024.0;
+
+// Geometry for a requested cell edge: dims per axis (capped), cell enlarged until the cell count
+// fits the budget and every capped axis still covers its extent.
+void make_geometry(const double lo[3], const double ext[3], double emax, double cell,
+                   double max_cells, GridGeom *g, uint32_t *ncell, double *cell_used) {
+    int dims[3];
+    for (;;) {
+        double total = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            double d = floor(ext[a] / cell) + 1.0;
+            if (d > kMaxDim) d = kMaxDim;
+            dims[a] = (int)d;
+            total *= d;
+        }
+        if (total <= max_cells) break;
+        cell *= 1.26;
+    }
+    for (int a = 0; a < 3; ++a)
+        if (ext[a] / cell >= (double)dims[a]) cell = ext[a] / (double)dims[a] * (1.0 + 1e-6);
+    g->ox = (float)lo[0];
+    g->oy = (float)lo[1];
+    g->oz = (float)lo[2];
+    g->cell = (float)cell;
+    g->inv = 1.0f / g->cell;
+    g->nx = dims[0];
+    g->ny = dims[1];
+    g->nz = dims[2];
+    g->slack = (float)(2e-6 * (emax + cell));
+    *ncell = (uint32_t)dims[0] * (uint32_t)dims[1] * (uint32_t)dims[2];
+    *cell_used = cell;
+}
+
+}  // namespace
+
+int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
+    pcrs_ctx *ctx = ix->ctx;
+    const uint32_t m = (uint32_t)ix->m;
+    ix->algo = PCRS_ALGO_BRUTE;
+    if (m == 0) return PCRS_OK;
+
+    // 1. bounding box of the finite points
+    const unsigned nb = grid_for(ctx, m, GB_THREADS);
+    DevBuf partials;
+    PCRS_HIP_CHECK(ctx, partials.alloc(nb * sizeof(BBoxPartial)));
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
+                       ix->z, m, partials.as<BBoxPartial>());
+    std::vector<BBoxPartial> hp(nb);
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hp.data(), partials.p, nb * sizeof(BBoxPartial),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    size_t nvalid = 0;
+    for (const BBoxPartial &p : hp) {
+        nvalid += p.nvalid;
+        for (int a = 0; a < 3; ++a) {
+            if (p.lo[a] < lo[a]) lo[a] = p.lo[a];
+            if (p.hi[a] > hi[a]) hi[a] = p.hi[a];
+        }
+    }
+    ix->nvalid = nvalid;
+    if (nvalid < 64) return PCRS_OK;  // brute force
+    double ext[3], emax = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = hi[a] - lo[a];
+        if (ext[a] > emax) emax = ext[a];
+    }
+    if (!(emax > 0.0) || !(emax < 1e30)) return PCRS_OK;  // coincident points or overflow
+
+    // 2. cell size: start from the bounding-box density, then shrink while the occupied cells
+    //    are much fuller than the target (surfaces and clusters leave most of the box empty).
+    //    Every attempt takes the full histogram with cell ids, so the accepted one is reused.
+    const double P = target_occupancy(k_hint);
+    double eff[3];
+    for (int a = 0; a < 3; ++a) eff[a] = ext[a] > 1e-3 * emax ? ext[a] : 1e-3 * emax;
+    double cell = cbrt(eff[0] * eff[1] * eff[2] * P / (double)nvalid);
+    const double max_cells = 4.0 * (double)nvalid + 4096.0;
+    GridGeom g{};
+    uint32_t ncell = 0;
+    DevBuf counts, cell_id;
+    PCRS_HIP_CHECK(ctx, cell_id.alloc((size_t)m * sizeof(uint32_t)));
+    for (int attempt = 0;; ++attempt) {
+        double used = cell;
+        make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
+        cell = used;
+        if (counts.bytes < ((size_t)ncell + 2) * sizeof(uint32_t)) {
+            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            PCRS_HIP_CHECK(ctx, counts.alloc(((size_t)ncell + 2) * sizeof(uint32_t)));
+        }
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
+                                           ctx->stream));
+        hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
+                           ix->y, ix->z, m, g, cell_id.as<uint32_t>(), counts.as<uint32_t>());
+        if (attempt == 3) break;
+        uint32_t *d_nonempty = counts.as<uint32_t>() + ncell + 1;
+        hipLaunchKernelGGL(nonempty_kernel, dim3(grid_for(ctx, ncell, GB_THREADS)),
+                           dim3(GB_THREADS), 0, ctx->stream, counts.as<uint32_t>(), ncell,
+                           d_nonempty);
+        uint32_t nonempty = 0;
+        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(&nonempty, d_nonempty, sizeof(uint32_t),
+                                           hipMemcpyDeviceToHost, ctx->stream));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const double occ = (double)nvalid / (double)(nonempty ? nonempty : 1);
+        if (occ <= 1.6 * P) break;
+        // occupied volume ~ nonempty * cell^3: re-aim at P points per occupied cell.  A surface
+        // responds with cell^2 rather than cell^3, hence the repeated attempts.
+        double shrink = cbrt(P / occ);
+        if (shrink < 0.4) shrink = 0.4;
+        double next = cell * shrink;
+        if (next < emax / kMaxDim) next = emax / kMaxDim;
+        GridGeom g2{};
+        uint32_t ncell2 = 0;
+        double used2 = next;
+        make_geometry(lo, ext, emax, next, max_cells, &g2, &ncell2, &used2);
+        if (used2 > 0.95 * cell) break;  // budget or dimension cap reached: keep this geometry
+        cell = next;
+    }
+
+    // 3. scan the histogram into slot ranges and scatter the points
+    DevBuf scan_sums, fill;
+    PCRS_TRY(exclusive_scan(ctx, counts.as<uint32_t>(), ncell, scan_sums));
+    PCRS_HIP_CHECK(ctx, fill.alloc((size_t)ncell * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(fill.p, counts.p, (size_t)ncell * sizeof(uint32_t),
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+    PCRS_HIP_CHECK(ctx, ix->spts.alloc(nvalid * sizeof(float4)));
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
+                       ix->z, m, cell_id.as<uint32_t>(), fill.as<uint32_t>(),
+                       ix->spts.as<float4>());
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    // the temporaries above are freed on return: wait for the kernels that use them
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ix->cell_start.release();
+    ix->cell_start.p = counts.p;  // take ownership of the scanned histogram
+    ix->cell_start.bytes = counts.bytes;
+    counts.p = nullptr;
+    counts.bytes = 0;
+    ix->g = g;
+    ix->ncell = ncell;
+    ix->algo = PCRS_ALGO_GRID;
+    return PCRS_OK;
+}
+
+// ----------------------------------------------------------------------------- host: query
+
+int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (q.nq == 0) return PCRS_OK;
+    if (q.nq >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    if (kneed == 0) kneed = 1;
+    const uint32_t keff = (uint32_t)((size_t)kneed < ix->nvalid ? kneed : ix->nvalid);
+    // Lists longer than the register budget go to the brute-force kernel, which handles any k.
+    if (keff > PCRS_KMAX_REG || keff == 0) {
+        ix->stats[2] = q.nq;
+        return pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, nullptr, nullptr,
+                                  0);
+    }
+    const bool nn_only = out.nn_idx && !out.idx && !out.dist && !out.count && !out.mean && !out.nx;
+    const uint32_t nq = (uint32_t)q.nq;
+
+    // two retry lists (ping-pong) + stage counters
+    const size_t list_elems = (size_t)nq + 64;
+    const size_t need = (2 * list_elems + 64) * sizeof(uint32_t);
+    if (ix->fail_lists.bytes < need) {
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(need));
+    }
+    uint32_t *listA = ix->fail_lists.as<uint32_t>();
+    uint32_t *listB = listA + list_elems;
+    uint32_t *counters = listB + list_elems;  // [0..2] failures after each cube stage, [3] owned
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(counters, 0, 16 * sizeof(uint32_t), ctx->stream));
+
+    CellArgs a{};
+    a.g = ix->g;
+    a.cell_start = ix->cell_start.as<uint32_t>();
+    a.spts = ix->spts.as<float4>();
+    a.nvalid = (uint32_t)ix->nvalid;
+    a.rx = ix->x;
+    a.ry = ix->y;
+    a.rz = ix->z;
+    a.qx = q.qx;
+    a.qy = q.qy;
+    a.qz = q.qz;
+    a.kcert = keff;
+    // neighbour identities are needed for everything except the SOR mean
+    const bool collect = out.idx || out.dist || out.count || out.nx;
+    uint32_t kc = 0;
+    if (out.idx || out.dist || out.count) kc = out.k;
+    if (out.nx && out.k_nrm > kc) kc = out.k_nrm;
+    if (kc > keff) kc = keff;
+    a.kcollect = collect ? (kc ? kc : 1) : 0;
+    const int kb = k_bucket(keff);
+
+    auto launch = [&](unsigned blocks) {
+        if (nn_only) {
+            hipLaunchKernelGGL(nn_cell_kernel, dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a,
+                               out);
+            return;
+        }
+#define PCRS_CELL_CALL(KK)                                                                      \
+    do {                                                                                        \
+        if (collect)                                                                            \
+            hipLaunchKernelGGL((knn_cell_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0,  \
+                               ctx->stream, a, out);                                            \
+        else                                                                                    \
+            hipLaunchKernelGGL((knn_cell_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
+                               ctx->stream, a, out);                                            \
+    } while (0)
+        PCRS_DISPATCH_K(kb, PCRS_CELL_CALL)
+#undef PCRS_CELL_CALL
+    };
+
+    // stage 1: the 27-cell cube over every query
+    a.R = 1;
+    a.fail_list = listA;
+    a.fail_count = &counters[0];
+    unsigned blocks1 = (unsigned)((nq + GB_THREADS - 1) / GB_THREADS);
+    if (q.self && !nn_only) {
+        a.q_begin = (uint32_t)q.out_offset;
+        a.q_len = nq;
+        if (q.out_offset == 0 && q.nq == ix->m) {
+            a.qmode = 0;  // the whole cloud, in sorted-slot order
+            a.nq = (uint32_t)ix->nvalid;
+            blocks1 = (unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS);
+        } else {
+            // a sub-range: compact its sorted slots first so that every wave is full
+            hipLaunchKernelGGL(owned_slots_kernel,
+                               dim3((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS)),
+                               dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(),
+                               (uint32_t)ix->nvalid, a.q_begin, a.q_len, listB, &counters[3]);
+            a.qmode = 3;
+            a.qlist = listB;
+            a.qcount = &counters[3];
+        }
+    } else {
+        a.qmode = 1;
+        a.nq = nq;
+    }
+    pcrs_timing_begin(ctx);
+    launch(blocks1);
+    pcrs_timing_end(ctx);
+
+    // stages 2 and 3: larger cubes over the failures (count known only on the device: fixed grid
+    // with a grid-stride loop).  Stage 1 in slot-list mode still reads listB, so the first retry
+    // writes its failures to a third region when needed.
+    const unsigned retry_blocks = (unsigned)std::min<size_t>((nq + GB_THREADS - 1) / GB_THREADS,
+                                                             (size_t)ctx->num_cus * 4);
+    const int radii[2] = {2, 4};
+    uint32_t *src = listA, *dst = listB;
+    for (int st = 0; st < 2; ++st) {
+        a.qmode = 2;
+        a.R = radii[st];
+        a.qlist = src;
+        a.qcount = &counters[st];
+        a.fail_list = dst;
+        a.fail_count = &counters[st + 1];
+        launch(retry_blocks);
+        std::swap(src, dst);
+    }
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    // stage 4: brute force over what is left
+    PCRS_TRY(pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, src, &counters[2],
+                                nq));
+    // self queries answered from the sorted array never saw the non-finite points of the range
+    if (q.self && !nn_only && ix->nvalid < ix->m)
+        PCRS_TRY(pcrs_launch_invalid_defaults(ctx, ix->x, ix->y, ix->z, q, out));
+    ix->stats_dev = counters;
+    ix->stats_nq = nq;
+    return PCRS_OK;
 }

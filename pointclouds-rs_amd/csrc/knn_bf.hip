@@ -127,6 +127,17 @@ __global__ __launch_bounds__(BF_THREADS) void consume_list_kernel(BfArgs a, KnnO
     consume(ListNbrs{keys}, cnt, qvalid, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, out);
 }
 
+// Self-query ranges answered from the sorted grid array never see their non-finite points:
+// this kernel writes the consumers' no-neighbour defaults for them.
+__global__ __launch_bounds__(BF_THREADS) void invalid_defaults_kernel(BfArgs a, KnnOut out) {
+    const uint32_t qi = blockIdx.x * BF_THREADS + threadIdx.x;
+    if (qi >= a.nq) return;
+    const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];
+    if (finite3(qx, qy, qz)) return;
+    uint64_t none[1] = {PCRS_EMPTY_KEY};
+    consume(RegNbrs<1>(none), 0u, false, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, out);
+}
+
 __global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -196,5 +207,22 @@ int pcrs_launch_knn_bf(pcrs_ctx *ctx, const float *rx, const float *ry, const fl
     hipLaunchKernelGGL(consume_list_kernel, grid, block, 0, ctx->stream, a, out);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
+int pcrs_launch_invalid_defaults(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
+                                 const KnnQuery &q, const KnnOut &out) {
+    if (q.nq == 0) return PCRS_OK;
+    BfArgs a{};
+    a.rx = rx;
+    a.ry = ry;
+    a.rz = rz;
+    a.qx = q.qx;
+    a.qy = q.qy;
+    a.qz = q.qz;
+    a.nq = (uint32_t)q.nq;
+    hipLaunchKernelGGL(invalid_defaults_kernel, dim3((unsigned)((q.nq + BF_THREADS - 1) / BF_THREADS)),
+                       dim3(BF_THREADS), 0, ctx->stream, a, out);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

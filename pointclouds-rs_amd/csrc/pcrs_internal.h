@@ -45,6 +45,12 @@ int pcrs_set_err(pcrs_ctx *ctx, int code, const char *fmt, ...);
 int pcrs_ctx_scratch(pcrs_ctx *ctx, size_t bytes, void **out);
 int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out);
 
+#define PCRS_TRY(expr)                  \
+    do {                                \
+        int _rc = (expr);               \
+        if (_rc != PCRS_OK) return _rc; \
+    } while (0)
+
 #define PCRS_HIP_CHECK(ctx, expr)                                                              \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -96,15 +102,15 @@ struct pcrs_index {
     int algo = PCRS_ALGO_BRUTE;  // resolved strategy (BRUTE or GRID)
     // grid (algo == GRID)
     GridGeom g{};
-    size_t nvalid = 0;       // finite points
+    size_t nvalid = 0;   // finite points
     uint32_t ncell = 0;
-    DevBuf cell_start;       // uint32 [ncell + 1] into the sorted arrays
-    DevBuf sx, sy, sz;       // float  [nvalid] sorted by cell
-    DevBuf sidx;             // uint32 [nvalid] original index of sorted slot
-    DevBuf slot_of;          // uint32 [m] sorted slot of original point (PCRS_NO_INDEX if non-finite)
-    // block decomposition for the tile kernel
-    int bx = 2, by = 2, bz = 2;  // cells per query block
+    DevBuf cell_start;   // uint32 [ncell + 1] slot ranges of the cells (x-fastest cell order)
+    DevBuf spts;         // float4 [nvalid] points sorted by cell: (x, y, z, original index bits)
+    DevBuf fail_lists;   // two uint32 [nq] retry lists + stage counters, grown on demand
+    // counters of the last query: read back lazily by pcrs_index_last_stats
     uint64_t stats[3] = {0, 0, 0};
+    const uint32_t *stats_dev = nullptr;  // device counters [3]: failures after cube stage 1, 2, 3
+    uint64_t stats_nq = 0;
 };
 
 // Output selection of a neighbour search.  Every pointer is nullable.
@@ -144,6 +150,9 @@ int pcrs_launch_knn_bf(pcrs_ctx *ctx, const float *rx, const float *ry, const fl
 // ---- grid (grid.hip)
 int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint);
 int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed);
+// consumer defaults for the non-finite queries of a self-query range (knn_bf.hip)
+int pcrs_launch_invalid_defaults(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
+                                 const KnnQuery &q, const KnnOut &out);
 
 // ---- misc kernels (misc.hip)
 int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint8_t *keep,

@@ -56,6 +56,7 @@ int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out) {
 
 void pcrs_timing_begin(pcrs_ctx *ctx) {
     if (!ctx->timing) return;
+    if (ctx->timing_depth++ > 0) return;
     if (ctx->ev_used == ctx->ev_start.size()) {
         hipEvent_t a = nullptr, b = nullptr;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
@@ -69,7 +70,10 @@ void pcrs_timing_begin(pcrs_ctx *ctx) {
 }
 
 void pcrs_timing_end(pcrs_ctx *ctx) {
-    if (!ctx->timing || ctx->ev_used >= ctx->ev_stop.size()) return;
+    if (!ctx->timing) return;
+    if (--ctx->timing_depth > 0) return;
+    ctx->timing_depth = 0;
+    if (ctx->ev_used >= ctx->ev_stop.size()) return;
     (void)hipEventRecord(ctx->ev_stop[ctx->ev_used], ctx->stream);
     ctx->ev_used++;
 }
@@ -176,6 +180,7 @@ int pcrs_ctx_timing(pcrs_ctx *ctx, int enable) {
     PCRS_TRY(bind_device(ctx));
     ctx->timing = enable != 0;
     ctx->ev_used = 0;
+    ctx->timing_depth = 0;
     return PCRS_OK;
 }
 

@@ -750,9 +750,8 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
         a.qmode = 1;
         a.nq = nq;
     }
-    pcrs_timing_begin(ctx);
+    pcrs_timing_begin(ctx);  // one bracket around all four stages of the search
     launch(blocks1);
-    pcrs_timing_end(ctx);
 
     // stages 2 and 3: larger cubes over the failures (count known only on the device: fixed grid
     // with a grid-stride loop).  Stage 1 in slot-list mode still reads listB, so the first retry
@@ -773,8 +772,10 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
     }
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     // stage 4: brute force over what is left
-    PCRS_TRY(pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, src, &counters[2],
-                                nq));
+    const int rc_bf = pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, src,
+                                         &counters[2], nq);
+    pcrs_timing_end(ctx);
+    PCRS_TRY(rc_bf);
     // self queries answered from the sorted array never saw the non-finite points of the range
     if (q.self && !nn_only && ix->nvalid < ix->m)
         PCRS_TRY(pcrs_launch_invalid_defaults(ctx, ix->x, ix->y, ix->z, q, out));

@@ -33,6 +33,7 @@ struct pcrs_ctx {
     bool timing = false;
     std::vector<hipEvent_t> ev_start, ev_stop;  // one pair per bracketed launch
     size_t ev_used = 0;
+    int timing_depth = 0;  // nested brackets collapse into the outermost one
 };
 
 // Brackets one launch of the dominant (neighbour-search) kernel with HIP events on the context's

@@ -232,7 +232,8 @@ def test_icp_with_tolerance_and_gate(hip, oracle):
         rc, ref, _ = oracle.icp(mode, src, tgt, tn, max_iter=50, tol=1e-5, max_d=1.0, algo=1)
         assert bool(res.converged) == bool(ref.converged)
         assert abs(int(res.num_iterations) - int(ref.num_iterations)) <= 1
-        assert abs(res.rmse - ref.rmse) <= 1e-4 * max(ref.rmse, 1e-3)
+        # rmse ends on the f32 noise floor of the coordinates (|p| ~ 5, ulp 4.8e-7)
+        assert abs(res.rmse - ref.rmse) <= 1e-4 * ref.rmse + 1e-6
     # max_iterations == 0: one metrics pass (icp.rs:190-197)
     res = hip.icp_register(0, src, tgt, None, 0, 1e-5, np.inf)
     rc, ref, _ = oracle.icp(0, src, tgt, None, max_iter=0, tol=1e-5, algo=1)

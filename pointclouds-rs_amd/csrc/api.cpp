@@ -277,15 +277,15 @@ int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]) {
     if (!index || !stats) return PCRS_ERR_INVALID_ARG;
     if (index->stats_dev) {
         pcrs_ctx *ctx = index->ctx;
-        uint32_t c[3] = {0, 0, 0};
+        uint32_t c[4] = {0, 0, 0, 0};
         if (hipSetDevice(ctx->device) != hipSuccess ||
             hipMemcpyAsync(c, index->stats_dev, sizeof(c), hipMemcpyDeviceToHost, ctx->stream) !=
                 hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             return PCRS_ERR_HIP;
         stats[0] = index->stats_nq - c[0];  // certified by the 27-cell cube
-        stats[1] = c[0] - c[2];             // certified by a larger cube
-        stats[2] = c[2];                    // brute force
+        stats[1] = c[0] - c[3];             // certified by a larger cube (wave-per-query)
+        stats[2] = c[3];                    // brute force
         return PCRS_OK;
     }
     for (int i = 0; i < 3; ++i) stats[i] = index->stats[i];

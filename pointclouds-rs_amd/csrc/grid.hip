@@ -390,6 +390,175 @@ __global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut
     }
 }
 
+// Retry kernel: ONE WAVE PER QUERY.  The queries that the per-lane kernel could not certify are
+// few and scattered, so a lane-per-query retry would be a handful of long serial walks.  Here the
+// 64 lanes of a wave share one query: they stride over each row of the (2R+1)^3 cube (coalesced
+// float4 loads), every lane keeps the K smallest distances of its share, and a 6-step xor
+// butterfly over ds_bpermute merges the 64 sorted lists so that all lanes end with the global K
+// smallest.  Identities, when needed, are gathered by a second walk with ballot-compacted appends
+// into a per-wave LDS list, ranked across lanes, and consumed by lane 0.
+template <int K, bool COLLECT>
+__global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut out) {
+    constexpr int WAVES = GB_THREADS / 64;
+    __shared__ uint32_t wl_slot[WAVES][64];
+    __shared__ uint64_t wl_key[WAVES][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t total = *a.qcount;
+    const GridGeom &g = a.g;
+    const int R = a.R;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (uint32_t pos = blockIdx.x * WAVES + w; pos < total; pos += gridDim.x * WAVES) {
+        const uint32_t qi = a.qlist[pos];
+        const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];  // finite: stage 1 filtered
+        const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+        const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
+        const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
+        const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+        const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+        const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+
+        float D[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
+        for (int zz = z0; zz <= z1; ++zz)
+            for (int yy = y0; yy <= y1; ++yy) {
+                const uint32_t row =
+                    ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                const uint32_t s0 = a.cell_start[row + x0], s1 = a.cell_start[row + x1 + 1];
+                for (uint32_t s = s0 + lane; s < s1; s += 64) {
+                    const float4 p = a.spts[s];
+                    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+#pragma unroll
+                    for (int t = K - 1; t > 0; --t)
+                        D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
+                    D[0] = fminf(D[0], d2);
+                }
+            }
+        // butterfly merge of the 64 per-lane lists
+#pragma unroll 1
+        for (int r = 1; r < 64; r <<= 1) {
+            float T[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) T[i] = D[i];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const float v = __shfl_xor(T[j], r, 64);
+#pragma unroll
+                for (int t = K - 1; t > 0; --t) D[t] = __builtin_amdgcn_fmed3f(v, D[t - 1], D[t]);
+                D[0] = fminf(D[0], v);
+            }
+        }
+
+        const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
+                           (z0 == 0) && (z1 == g.nz - 1);
+        bool certified = whole;
+        float tau_cert = __builtin_inff();
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if ((uint32_t)i == a.kcert - 1) tau_cert = D[i];
+        if (!whole) {
+            float margin = __builtin_inff();
+            const float u[3] = {ux, uy, uz};
+            const int c[3] = {cx, cy, cz};
+            const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                if (c[ax] + R < n[ax] - 1)
+                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+            }
+            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
+            certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
+        }
+        bool failed = !certified;
+
+        uint32_t have = 0;
+        if (!failed && COLLECT) {
+            float tau = __builtin_inff();
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                if ((uint32_t)i == a.kcollect - 1) tau = D[i];
+            uint32_t base = 0;
+            for (int zz = z0; zz <= z1; ++zz)
+                for (int yy = y0; yy <= y1; ++yy) {
+                    const uint32_t row =
+                        ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                    const uint32_t s0 = a.cell_start[row + x0], s1 = a.cell_start[row + x1 + 1];
+                    for (uint32_t sb = s0; sb < s1; sb += 64) {
+                        const uint32_t s = sb + lane;
+                        bool hit = false;
+                        if (s < s1) {
+                            const float4 p = a.spts[s];
+                            hit = sqdist(qx, qy, qz, p.x, p.y, p.z) <= tau;
+                        }
+                        const unsigned long long mask = __ballot(hit);
+                        if (hit) {
+                            const uint32_t at = base + (uint32_t)__popcll(mask & lt_mask);
+                            if (at < 64u) wl_slot[w][at] = s;
+                        }
+                        base += (uint32_t)__popcll(mask);
+                    }
+                }
+            if (base > 64u) {
+                failed = true;  // more ties at the K-th distance than the list holds
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint64_t key = PCRS_EMPTY_KEY;
+                if ((uint32_t)lane < base) {
+                    const float4 p = a.spts[wl_slot[w][lane]];
+                    key = make_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+                }
+                uint32_t rank = 0;
+                for (uint32_t i = 0; i < base; ++i) {
+                    const uint32_t lo = __shfl((uint32_t)key, (int)i, 64);
+                    const uint32_t hi = __shfl((uint32_t)(key >> 32), (int)i, 64);
+                    const uint64_t other = ((uint64_t)hi << 32) | lo;
+                    rank += (other < key) ? 1u : 0u;
+                }
+                if ((uint32_t)lane < base) wl_key[w][rank] = key;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                have = base < a.kcollect ? base : a.kcollect;
+            }
+        }
+        if (failed) {
+            if (lane == 0 && a.fail_list) {
+                const uint32_t f = atomicAdd(a.fail_count, 1u);
+                a.fail_list[f] = qi;
+            }
+            continue;
+        }
+        if (lane == 0) {
+            if (out.mean) {
+                const uint32_t kk = out.k_sor + 1u;
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < K; ++i)
+                    c += ((uint32_t)i < kk && D[i] < __builtin_inff()) ? 1u : 0u;
+                const uint32_t first = c > 1u ? 1u : 0u;
+                float mean = __builtin_inff();
+                if (c - first > 0u) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < K; ++i)
+                        if ((uint32_t)i >= first && (uint32_t)i < c) sum += sqrtf(D[i]);
+                    mean = sum / (float)(c - first);
+                }
+                out.mean[qi] = mean;
+            }
+            if (COLLECT) {
+                KnnOut o2 = out;
+                o2.mean = nullptr;
+                consume(ListNbrs{&wl_key[w][0]}, have, true, (size_t)qi, qx, qy, qz, a.rx, a.ry,
+                        a.rz, o2);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lists are reused next round
+    }
+}
+
 // Sorted slots whose original index lies in [q_begin, q_begin + q_len), in (approximately)
 // slot order, so that a sub-range of a cloud is still processed with full waves.
 __global__ __launch_bounds__(GB_THREADS) void owned_slots_kernel(const float4 *spts,
@@ -681,7 +850,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
     }
     uint32_t *listA = ix->fail_lists.as<uint32_t>();
     uint32_t *listB = listA + list_elems;
-    uint32_t *counters = listB + list_elems;  // [0..2] failures after each cube stage, [3] owned
+    uint32_t *counters = listB + list_elems;  // [0..3] failures after each cube stage, [4] owned
     PCRS_HIP_CHECK(ctx, hipMemsetAsync(counters, 0, 16 * sizeof(uint32_t), ctx->stream));
 
     CellArgs a{};
@@ -702,7 +871,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
     if (out.idx || out.dist || out.count) kc = out.k;
     if (out.nx && out.k_nrm > kc) kc = out.k_nrm;
     if (kc > keff) kc = keff;
-    a.kcollect = collect ? (kc ? kc : 1) : 0;
+    a.kcollect = (collect || nn_only) ? (kc ? kc : 1) : 0;
     const int kb = k_bucket(keff);
 
     auto launch = [&](unsigned blocks) {
@@ -741,10 +910,10 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
             hipLaunchKernelGGL(owned_slots_kernel,
                                dim3((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS)),
                                dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(),
-                               (uint32_t)ix->nvalid, a.q_begin, a.q_len, listB, &counters[3]);
+                               (uint32_t)ix->nvalid, a.q_begin, a.q_len, listB, &counters[4]);
             a.qmode = 3;
             a.qlist = listB;
-            a.qcount = &counters[3];
+            a.qcount = &counters[4];
         }
     } else {
         a.qmode = 1;
@@ -753,27 +922,39 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
     pcrs_timing_begin(ctx);  // one bracket around all four stages of the search
     launch(blocks1);
 
-    // stages 2 and 3: larger cubes over the failures (count known only on the device: fixed grid
-    // with a grid-stride loop).  Stage 1 in slot-list mode still reads listB, so the first retry
-    // writes its failures to a third region when needed.
-    const unsigned retry_blocks = (unsigned)std::min<size_t>((nq + GB_THREADS - 1) / GB_THREADS,
-                                                             (size_t)ctx->num_cus * 4);
-    const int radii[2] = {2, 4};
+    // stages 2-4: larger cubes over the failures, one wave per query (their number is known only
+    // on the device: fixed grid with a grid-stride loop)
+    auto launch_wave = [&](unsigned blocks) {
+        const bool coll = collect || nn_only;
+#define PCRS_WAVE_CALL(KK)                                                                      \
+    do {                                                                                        \
+        if (coll)                                                                               \
+            hipLaunchKernelGGL((knn_wave_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0,  \
+                               ctx->stream, a, out);                                            \
+        else                                                                                    \
+            hipLaunchKernelGGL((knn_wave_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
+                               ctx->stream, a, out);                                            \
+    } while (0)
+        PCRS_DISPATCH_K(kb, PCRS_WAVE_CALL)
+#undef PCRS_WAVE_CALL
+    };
+    const unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);
+    const int radii[3] = {2, 4, 8};
     uint32_t *src = listA, *dst = listB;
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < 3; ++st) {
         a.qmode = 2;
         a.R = radii[st];
         a.qlist = src;
         a.qcount = &counters[st];
         a.fail_list = dst;
         a.fail_count = &counters[st + 1];
-        launch(retry_blocks);
+        launch_wave(retry_blocks);
         std::swap(src, dst);
     }
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     // stage 4: brute force over what is left
     const int rc_bf = pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, src,
-                                         &counters[2], nq);
+                                         &counters[3], nq);
     pcrs_timing_end(ctx);
     PCRS_TRY(rc_bf);
     // self queries answered from the sorted array never saw the non-finite points of the range

@@ -110,7 +110,7 @@ struct pcrs_index {
     DevBuf fail_lists;   // two uint32 [nq] retry lists + stage counters, grown on demand
     // counters of the last query: read back lazily by pcrs_index_last_stats
     uint64_t stats[3] = {0, 0, 0};
-    const uint32_t *stats_dev = nullptr;  // device counters [3]: failures after cube stage 1, 2, 3
+    const uint32_t *stats_dev = nullptr;  // device counters [4]: failures after cube stages 1-4
     uint64_t stats_nq = 0;
 };
 

@@ -249,7 +249,15 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
             const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
             const uint32_t s0 = a.cell_start[row + x0];
             const uint32_t s1 = a.cell_start[row + x1 + 1];
-            for (uint32_t s = s0; s < s1; ++s) f(a.spts[s], s);
+            // two loads in flight per iteration: the walk is latency-sensitive
+            uint32_t s = s0;
+            for (; s + 1 < s1; s += 2) {
+                const float4 p0 = a.spts[s];
+                const float4 p1 = a.spts[s + 1];
+                f(p0, s);
+                f(p1, s + 1);
+            }
+            if (s < s1) f(a.spts[s], s);
         }
     }
 }
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut
         const bool qvalid = finite3(qx, qy, qz);
         if (!qvalid) {  // no neighbours: the consumers write their defaults
             uint64_t none[1] = {PCRS_EMPTY_KEY};
-            consume(RegNbrs<1>(none), 0u, false, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, out);
+            consume(RegNbrs<1>(none, a.rx, a.ry, a.rz), 0u, false, (size_t)qi, qx, qy, qz, out);
             continue;
         }
         const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
@@ -375,17 +383,18 @@ __global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut
                 }
                 continue;
             }
-            TopK<K> top;
+            TopK<K, true> top;
             top.init(true);
             for (uint32_t j = 0; j < cnt; ++j) {
-                const float4 p = a.spts[lst[j][threadIdx.x]];
-                top.offer(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+                const uint32_t slot = lst[j][threadIdx.x];
+                const float4 p = a.spts[slot];
+                top.offer(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w), slot);
             }
             KnnOut o2 = out;
             o2.mean = nullptr;  // already written from D[]
             uint32_t have = top.count();
             if (have > a.kcollect) have = a.kcollect;
-            consume(RegNbrs<K>(top.key), have, true, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, o2);
+            consume(SlotNbrs<K>(top.key, top.pay, a.spts), have, true, (size_t)qi, qx, qy, qz, o2);
         }
     }
 }
@@ -551,8 +560,8 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             if (COLLECT) {
                 KnnOut o2 = out;
                 o2.mean = nullptr;
-                consume(ListNbrs{&wl_key[w][0]}, have, true, (size_t)qi, qx, qy, qz, a.rx, a.ry,
-                        a.rz, o2);
+                consume(ListNbrs{&wl_key[w][0], a.rx, a.ry, a.rz}, have, true, (size_t)qi, qx, qy,
+                        qz, o2);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lists are reused next round

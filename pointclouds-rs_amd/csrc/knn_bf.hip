@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BF_THREADS) void knn_bf_kernel(BfArgs a, KnnOut out
         a.lo_io[qi] = (last == PCRS_EMPTY_KEY) ? PCRS_EMPTY_KEY : last + 1;
         return;
     }
-    consume(RegNbrs<K>(top.key), top.count(), qvalid, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz,
+    consume(RegNbrs<K>(top.key, a.rx, a.ry, a.rz), top.count(), qvalid, (size_t)qi, qx, qy, qz,
             out);
 }
 
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BF_THREADS) void consume_list_kernel(BfArgs a, KnnO
     const uint64_t *keys = a.list_keys + (size_t)qi * a.list_stride;
     uint32_t cnt = 0;
     while (cnt < a.list_stride && keys[cnt] != PCRS_EMPTY_KEY) ++cnt;
-    consume(ListNbrs{keys}, cnt, qvalid, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, out);
+    consume(ListNbrs{keys, a.rx, a.ry, a.rz}, cnt, qvalid, (size_t)qi, qx, qy, qz, out);
 }
 
 // Self-query ranges answered from the sorted grid array never see their non-finite points:
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BF_THREADS) void invalid_defaults_kernel(BfArgs a, 
     const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];
     if (finite3(qx, qy, qz)) return;
     uint64_t none[1] = {PCRS_EMPTY_KEY};
-    consume(RegNbrs<1>(none), 0u, false, (size_t)qi, qx, qy, qz, a.rx, a.ry, a.rz, out);
+    consume(RegNbrs<1>(none, a.rx, a.ry, a.rz), 0u, false, (size_t)qi, qx, qy, qz, out);
 }
 
 __global__ void fill_u64_kernel(uint64_t *p, size_t n, uint64_t v) {

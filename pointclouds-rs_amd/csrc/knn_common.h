@@ -33,36 +33,47 @@ __device__ __forceinline__ uint64_t make_key(float d2, uint32_t idx) {
 __device__ __forceinline__ float key_d2(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
 __device__ __forceinline__ uint32_t key_idx(uint64_t key) { return 0xFFFFFFFEu - (uint32_t)key; }
 
-// Ascending list of the K smallest keys seen, entirely in registers.
-template <int K>
+// Ascending list of the K smallest keys seen, entirely in registers.  With PAY, every key
+// carries a 32-bit payload (the grid kernels store the sorted slot of the point there, so that
+// the consumers can re-read its coordinates with one coherent float4 load).
+template <int K, bool PAY = false>
 struct TopK {
     uint64_t key[K];
+    uint32_t pay[PAY ? K : 1];
     float worst;  // d2 of key[K-1]; +inf while the list is not full
 
     __device__ __forceinline__ void init(bool active) {
 #pragma unroll
         for (int i = 0; i < K; ++i) key[i] = PCRS_EMPTY_KEY;
+        if (PAY) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) pay[PAY ? i : 0] = 0u;
+        }
         // an inactive lane can never pass `d2 <= worst` (d2 >= 0 or NaN)
         worst = active ? __builtin_inff() : -1.0f;
     }
 
     // Requires nk < key[K-1].
-    __device__ __forceinline__ void insert(uint64_t nk) {
+    __device__ __forceinline__ void insert(uint64_t nk, uint32_t np = 0u) {
 #pragma unroll
         for (int s = K - 1; s > 0; --s) {
-            uint64_t lower = key[s - 1];
-            uint64_t cur = key[s];
-            key[s] = (nk < lower) ? lower : ((nk < cur) ? nk : cur);
+            const uint64_t lower = key[s - 1];
+            const uint64_t cur = key[s];
+            const bool below = nk < lower, here = nk < cur;
+            key[s] = below ? lower : (here ? nk : cur);
+            if (PAY) pay[PAY ? s : 0] = below ? pay[PAY ? s - 1 : 0] : (here ? np : pay[PAY ? s : 0]);
         }
-        key[0] = (nk < key[0]) ? nk : key[0];
+        const bool first = nk < key[0];
+        key[0] = first ? nk : key[0];
+        if (PAY) pay[0] = first ? np : pay[0];
         worst = key_d2(key[K - 1]);  // the empty key decodes to +inf
     }
 
-    __device__ __forceinline__ void offer(float d2, uint32_t idx) {
+    __device__ __forceinline__ void offer(float d2, uint32_t idx, uint32_t np = 0u) {
         // NaN d2 (non-finite reference point) fails the compare and is dropped.
         if (d2 <= worst) {
-            uint64_t nk = make_key(d2, idx);
-            if (nk < key[K - 1]) insert(nk);
+            const uint64_t nk = make_key(d2, idx);
+            if (nk < key[K - 1]) insert(nk, np);
         }
     }
 
@@ -74,24 +85,64 @@ struct TopK {
     }
 };
 
-// Neighbour accessors for the consumers: `for_each(c, f)` calls f(j, key_j) for j < c in order.
+// Neighbour accessors for the consumers: `for_each(c, f)` calls f(j, key_j, payload_j) for j < c in
+// order; `fetch(key, payload, x, y, z)` yields the neighbour's coordinates.
 template <int K>
-struct RegNbrs {
+struct RegNbrs {  // keys in registers, coordinates gathered from the original columns by index
     const uint64_t (&key)[K];
-    __device__ __forceinline__ explicit RegNbrs(const uint64_t (&k)[K]) : key(k) {}
+    const float *rx, *ry, *rz;
+    __device__ __forceinline__ RegNbrs(const uint64_t (&k)[K], const float *x, const float *y,
+                                       const float *z)
+        : key(k), rx(x), ry(y), rz(z) {}
     template <class F>
     __device__ __forceinline__ void for_each(uint32_t c, F f) const {
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            if ((uint32_t)j < c) f((uint32_t)j, key[j]);
+            if ((uint32_t)j < c) f((uint32_t)j, key[j], 0u);
+    }
+    __device__ __forceinline__ void fetch(uint64_t k, uint32_t, float &x, float &y, float &z) const {
+        const uint32_t id = key_idx(k);
+        x = rx[id];
+        y = ry[id];
+        z = rz[id];
     }
 };
 
-struct ListNbrs {
-    const uint64_t *key;  // ascending keys of this query in global memory
+template <int K>
+struct SlotNbrs {  // keys + sorted-slot payloads in registers, coordinates from the sorted array
+    const uint64_t (&key)[K];
+    const uint32_t (&pay)[K];
+    const float4 *spts;
+    __device__ __forceinline__ SlotNbrs(const uint64_t (&k)[K], const uint32_t (&p)[K],
+                                        const float4 *s)
+        : key(k), pay(p), spts(s) {}
     template <class F>
     __device__ __forceinline__ void for_each(uint32_t c, F f) const {
-        for (uint32_t j = 0; j < c; ++j) f(j, key[j]);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if ((uint32_t)j < c) f((uint32_t)j, key[j], pay[j]);
+    }
+    __device__ __forceinline__ void fetch(uint64_t, uint32_t slot, float &x, float &y,
+                                          float &z) const {
+        const float4 p = spts[slot];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+    }
+};
+
+struct ListNbrs {  // ascending keys of this query in memory
+    const uint64_t *key;
+    const float *rx, *ry, *rz;
+    template <class F>
+    __device__ __forceinline__ void for_each(uint32_t c, F f) const {
+        for (uint32_t j = 0; j < c; ++j) f(j, key[j], 0u);
+    }
+    __device__ __forceinline__ void fetch(uint64_t k, uint32_t, float &x, float &y, float &z) const {
+        const uint32_t id = key_idx(k);
+        x = rx[id];
+        y = ry[id];
+        z = rz[id];
     }
 };
 
@@ -153,17 +204,16 @@ __device__ inline void smallest_eigvec_3x3(float f00, float f01, float f02, floa
 }
 
 // Per-query consumers.  `cnt` = valid neighbours available (ascending), `qvalid` = finite query,
-// `qo` = output slot, (rx,ry,rz) = reference columns in original order for the normals gather.
+// `qo` = output slot; neighbour coordinates come from the accessor's fetch().
 template <class Nbrs>
 __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvalid, size_t qo,
-                                        float qx, float qy, float qz, const float *rx,
-                                        const float *ry, const float *rz, const KnnOut &o) {
+                                        float qx, float qy, float qz, const KnnOut &o) {
     if (!qvalid) cnt = 0;
     if (o.idx || o.dist || o.count) {
         const uint32_t c = cnt < o.k ? cnt : o.k;
         if (o.count) o.count[qo] = c;
         const size_t base = qo * (size_t)o.k;
-        nb.for_each(c, [&](uint32_t j, uint64_t key) {
+        nb.for_each(c, [&](uint32_t j, uint64_t key, uint32_t) {
             if (o.idx) o.idx[base + j] = key_idx(key);
             if (o.dist) o.dist[base + j] = sqrtf(key_d2(key));  // kdtree.rs:76
         });
@@ -175,7 +225,7 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
     if (o.nn_idx) {
         uint32_t id = PCRS_NO_INDEX;
         float d2 = __builtin_inff();
-        nb.for_each(cnt < 1u ? cnt : 1u, [&](uint32_t, uint64_t key) {
+        nb.for_each(cnt < 1u ? cnt : 1u, [&](uint32_t, uint64_t key, uint32_t) {
             id = key_idx(key);
             d2 = key_d2(key);
         });
@@ -192,7 +242,7 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
             const uint32_t nn = c - first;
             if (nn > 0u) {
                 float sum = 0.0f;
-                nb.for_each(c, [&](uint32_t j, uint64_t key) {
+                nb.for_each(c, [&](uint32_t j, uint64_t key, uint32_t) {
                     if (j >= first) sum += sqrtf(key_d2(key));
                 });
                 mean = sum / (float)nn;
@@ -207,21 +257,23 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
         if (c >= 1u) {
             const float count = (float)c;
             float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-            nb.for_each(c, [&](uint32_t, uint64_t key) {
-                const uint32_t id = key_idx(key);
-                cx += rx[id];
-                cy += ry[id];
-                cz += rz[id];
+            nb.for_each(c, [&](uint32_t, uint64_t key, uint32_t pay) {
+                float px, py, pz;
+                nb.fetch(key, pay, px, py, pz);
+                cx += px;
+                cy += py;
+                cz += pz;
             });
             cx /= count;
             cy /= count;
             cz /= count;
             float c00 = 0.0f, c01 = 0.0f, c02 = 0.0f, c11 = 0.0f, c12 = 0.0f, c22 = 0.0f;
-            nb.for_each(c, [&](uint32_t, uint64_t key) {
-                const uint32_t id = key_idx(key);
-                const float dx = rx[id] - cx;
-                const float dy = ry[id] - cy;
-                const float dz = rz[id] - cz;
+            nb.for_each(c, [&](uint32_t, uint64_t key, uint32_t pay) {
+                float px, py, pz;
+                nb.fetch(key, pay, px, py, pz);
+                const float dx = px - cx;
+                const float dy = py - cy;
+                const float dz = pz - cz;
                 c00 += dx * dx;
                 c01 += dx * dy;
                 c02 += dx * dz;

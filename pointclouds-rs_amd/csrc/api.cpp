@@ -1010,19 +1010,27 @@ int pcrs_icp_register(pcrs_ctx *ctx, int mode, const float *sx, const float *sy,
 
 }  // extern "C"
 
-// v1 of the global SOR statistics: bring the means to the host and sum them left to right there,
-// which is the only order that reproduces the reference's f32 threshold bit for bit.
+// Global SOR statistics: computed on the device with the reference's summation order
+// (stats.hip); only the few scalars come back.
 int pcrs_sor_threshold_impl(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul, float *thr,
                             int *has_finite) {
     *thr = std::numeric_limits<float>::quiet_NaN();
     *has_finite = 0;
     if (n == 0) return PCRS_OK;
+    const size_t sb = (pcrs_sor_stats_scalars_bytes() + 63) & ~(size_t)63;
+    const size_t wb = pcrs_sor_stats_workspace(n);
+    void *scratch = nullptr;
+    PCRS_TRY(pcrs_ctx_scratch(ctx, sb + wb, &scratch));
     void *pin = nullptr;
-    PCRS_TRY(pcrs_ctx_pinned(ctx, n * sizeof(float), &pin));
-    PCRS_TRY(download(ctx, pin, dmean, n * sizeof(float)));
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sb, &pin));
+    PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean, n, std_mul, scratch,
+                                   reinterpret_cast<char *>(scratch) + sb, wb));
+    PCRS_TRY(download(ctx, pin, scratch, pcrs_sor_stats_scalars_bytes()));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     float t;
-    if (host_threshold(reinterpret_cast<const float *>(pin), n, std_mul, &t)) {
+    int ok;
+    pcrs_sor_stats_decode(pin, nullptr, &t, &ok);
+    if (ok) {
         *thr = t;
         *has_finite = 1;
     }

@@ -170,7 +170,14 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            const float *tz, const float *tnx, const float *tny, const float *tnz,
                            const uint32_t *nn_idx, const float *nn_d2, float max_d,
                            uint32_t *tgt_idx_out, float *dist_out, double *d_sums);
-// exact reproduction of a left-to-right f32 sum (stats.hip)
+// SOR global statistics with the reference's left-to-right f32 summation, on the device (stats.hip)
+size_t pcrs_sor_stats_workspace(size_t n);
+size_t pcrs_sor_stats_scalars_bytes();
+int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
+                          void *d_scalars, void *d_work, size_t work_bytes);
+int pcrs_launch_mask_dev_thr(pcrs_ctx *ctx, const float *mean, size_t n, const void *d_scalars,
+                             uint8_t *keep, unsigned long long *d_count);
+void pcrs_sor_stats_decode(const void *host_copy, float *mu, float *thr, int *has_finite);
 int pcrs_sor_threshold_impl(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
                             float *thr, int *has_finite);
 

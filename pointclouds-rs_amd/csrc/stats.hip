@@ -1,0 +1,346 @@
+// Global statistics of statistical_outlier_removal on the GPU, bit-identical to the reference's
+// strictly left-to-right f32 sums (crates/filters/src/statistical_outlier.rs:43-62):
+//     mu = (sum of finite means) / nf ;  var = (sum of (d - mu)^2) / nf ;  thr = mu + mul*sqrt(var)
+//
+// A left-to-right f32 sum is not associative, but while the running sum s stays inside one
+// binade [2^e, 2^(e+1)) its ulp u = 2^(e-23) is fixed and s/u is an integer S in [2^23, 2^24).
+// Adding a non-negative x = (X + f) u then gives S + X, rounded up when f > 1/2 and to even when
+// f = 1/2 exactly.  So each element is a function S -> S + a[S & 1], and such functions compose
+// associatively: (f then g)[p] = f[p] + g[(p + f[p]) & 1].  That turns the sequential sum into a
+// scan wherever the binade does not change:
+//   1. per 256-element chunk: f64 sum + finite count                      (parallel)
+//   2. exclusive scan of the chunk sums -> a close estimate of s at every chunk start
+//   3. per chunk: composite function under the binade of that estimate    (parallel)
+//   4. one wave walks the chunks in order with the true f32 state: a chunk whose composite
+//      applies (same binade going in, still inside it coming out) costs O(1); any other chunk
+//      (a binade crossing, the first elements, a wrong estimate) is summed element by element
+//      with real f32 adds.  The result is exact by construction; only speed depends on 1-3.
+#include "knn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace pcrs {
+
+constexpr int ST_CHUNK = 256;           // elements per chunk = one wave x 4
+constexpr int ST_PER_LANE = ST_CHUNK / 64;
+constexpr uint32_t ST_SAT = 1u << 30;   // saturation of composite increments (>= 2^24 means "left the binade")
+constexpr int ST_NO_BINADE = -1000;
+
+struct StatsScalars {
+    float mu;
+    float thr;
+    float sigma;
+    uint32_t has_finite;
+    unsigned long long nf;
+};
+
+struct Composite {
+    uint32_t a0, a1;  // increment of S for even / odd S
+    int e;            // binade the composite was built for, ST_NO_BINADE = unusable
+    uint32_t pad;
+};
+
+// element i of pass P: pass 1 = finite mean (else 0), pass 2 = (mean - mu)^2 of finite means
+template <int PASS>
+__device__ __forceinline__ float stat_element(const float *mean, size_t n, size_t i, float mu,
+                                              bool *finite) {
+    *finite = false;
+    if (i >= n) return 0.0f;
+    const float d = mean[i];
+    if (!(d - d == 0.0f)) return 0.0f;  // inf / NaN are filtered out (:43-47)
+    *finite = true;
+    if (PASS == 1) return d;
+    const float t = d - mu;
+    return t * t;  // (d - global_mean).powi(2)
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void chunk_sums_kernel(const float *mean, size_t n,
+                                                         const StatsScalars *sc, double *csum,
+                                                         uint32_t *ccnt, uint32_t nchunks) {
+    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const float mu = (PASS == 2) ? sc->mu : 0.0f;
+    double s = 0.0;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < ST_PER_LANE; ++k) {
+        bool fin;
+        const float x = stat_element<PASS>(mean, n, (size_t)chunk * ST_CHUNK + lane * ST_PER_LANE + k, mu, &fin);
+        s += (double)x;
+        c += fin ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        c += __shfl_down(c, off, 64);
+    }
+    if (lane == 0) {
+        csum[chunk] = s;
+        ccnt[chunk] = c;
+    }
+}
+
+// exclusive f64 scan of the chunk sums (in place) and the total finite count
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(double *csum, const uint32_t *ccnt,
+                                                          uint32_t nchunks, StatsScalars *sc,
+                                                          int write_count) {
+    __shared__ double wsum[16];
+    __shared__ unsigned long long wcnt[16];
+    __shared__ double carry_s;
+    __shared__ unsigned long long carry_c;
+    if (threadIdx.x == 0) {
+        carry_s = 0.0;
+        carry_c = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nchunks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const double v = (i < nchunks) ? csum[i] : 0.0;
+        unsigned long long c = (i < nchunks) ? ccnt[i] : 0;
+        double incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 63) wsum[wave] = incl;
+        if (lane == 0) wcnt[wave] = c;
+        __syncthreads();
+        double wave_off = 0.0;
+        for (int w = 0; w < wave; ++w) wave_off += wsum[w];
+        const double carry = carry_s;
+        if (i < nchunks) csum[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+        if (threadIdx.x == 0) {
+            unsigned long long t = carry_c;
+            for (int w = 0; w < 16; ++w) t += wcnt[w];
+            carry_c = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && write_count) {
+        sc->nf = carry_c;
+        sc->has_finite = carry_c ? 1u : 0u;
+    }
+}
+
+__device__ __forceinline__ Composite compose(const Composite &f, const Composite &g) {
+    // f first, then g
+    Composite h;
+    const uint32_t g0 = ((0u + f.a0) & 1u) ? g.a1 : g.a0;
+    const uint32_t g1 = ((1u + f.a1) & 1u) ? g.a1 : g.a0;
+    h.a0 = min(f.a0 + g0, ST_SAT);
+    h.a1 = min(f.a1 + g1, ST_SAT);
+    h.e = f.e;
+    h.pad = 0;
+    return h;
+}
+
+// the function S -> S + a[S & 1] of one element x >= 0 in the binade with ulp 2^(e-23)
+__device__ __forceinline__ Composite element_function(float x, int e) {
+    Composite f;
+    f.e = e;
+    f.pad = 0;
+    const double t = ldexp((double)x, 23 - e);  // x / ulp, exact
+    if (t >= (double)ST_SAT) {
+        f.a0 = f.a1 = ST_SAT;
+        return f;
+    }
+    const double fl = floor(t);
+    const double fr = t - fl;
+    const uint32_t X = (uint32_t)fl;
+    if (fr < 0.5) {
+        f.a0 = f.a1 = X;
+    } else if (fr > 0.5) {
+        f.a0 = f.a1 = X + 1u;
+    } else {  // tie: round to even
+        f.a0 = X + ((X & 1u) ? 1u : 0u);         // S even: S + X odd iff X odd
+        f.a1 = X + ((X & 1u) ? 0u : 1u);         // S odd:  S + X odd iff X even
+    }
+    return f;
+}
+
+__device__ __forceinline__ int binade_of(float s) {
+    const uint32_t b = __float_as_uint(s);
+    const int ex = (int)((b >> 23) & 0xFFu);
+    if (ex == 0 || ex == 255 || (b >> 31)) return ST_NO_BINADE;
+    const int e = ex - 127;
+    if (e < -100 || e > 100) return ST_NO_BINADE;
+    return e;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean, size_t n,
+                                                              const StatsScalars *sc,
+                                                              const double *cpre, Composite *comp,
+                                                              uint32_t nchunks) {
+    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const float mu = (PASS == 2) ? sc->mu : 0.0f;
+    const int e = binade_of((float)cpre[chunk]);
+    Composite f;
+    f.a0 = f.a1 = 0;
+    f.e = e;
+    f.pad = 0;
+    if (e != ST_NO_BINADE) {
+#pragma unroll
+        for (int k = 0; k < ST_PER_LANE; ++k) {
+            bool fin;
+            const float x = stat_element<PASS>(mean, n, (size_t)chunk * ST_CHUNK + lane * ST_PER_LANE + k, mu, &fin);
+            f = compose(f, element_function(x, e));
+        }
+        // ordered tree: lane l absorbs lane l + off (the later elements)
+        for (int off = 1; off < 64; off <<= 1) {
+            Composite g;
+            g.a0 = __shfl_down(f.a0, off, 64);
+            g.a1 = __shfl_down(f.a1, off, 64);
+            g.e = e;
+            g.pad = 0;
+            if ((lane & (2 * off - 1)) == 0) f = compose(f, g);
+        }
+    }
+    if (lane == 0) comp[chunk] = f;
+}
+
+// One wave walks the chunks in order carrying the exact f32 running sum.
+template <int PASS>
+__global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_t n,
+                                                        StatsScalars *sc, const Composite *comp,
+                                                        uint32_t nchunks, float std_mul) {
+    const int lane = threadIdx.x;
+    const float mu = (PASS == 2) ? sc->mu : 0.0f;
+    float s = 0.0f;  // uniform across the wave
+    for (uint32_t base = 0; base < nchunks; base += 64) {
+        Composite mine;
+        mine.a0 = mine.a1 = 0;
+        mine.e = ST_NO_BINADE;
+        mine.pad = 0;
+        if (base + lane < nchunks) mine = comp[base + lane];
+        const uint32_t lim = min(64u, nchunks - base);
+        for (uint32_t j = 0; j < lim; ++j) {
+            const uint32_t a0 = __builtin_amdgcn_readlane(mine.a0, j);
+            const uint32_t a1 = __builtin_amdgcn_readlane(mine.a1, j);
+            const int e = (int)__builtin_amdgcn_readlane((uint32_t)mine.e, j);
+            const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+            bool done = false;
+            if (e != ST_NO_BINADE && binade_of(__uint_as_float(bits)) == e) {
+                const uint32_t S = (bits & 0x7FFFFFu) | 0x800000u;
+                const uint32_t S2 = S + ((S & 1u) ? a1 : a0);
+                if (S2 < (1u << 24)) {
+                    s = __uint_as_float((bits & 0xFF800000u) | (S2 & 0x7FFFFFu));
+                    done = true;
+                }
+            }
+            if (!done) {
+                // element-by-element f32 adds over this chunk (lane-major element order)
+                float v[ST_PER_LANE];
+#pragma unroll
+                for (int k = 0; k < ST_PER_LANE; ++k) {
+                    bool fin;
+                    v[k] = stat_element<PASS>(mean, n, (size_t)(base + j) * ST_CHUNK + lane * ST_PER_LANE + k, mu, &fin);
+                }
+                for (int l = 0; l < 64; ++l) {
+#pragma unroll
+                    for (int k = 0; k < ST_PER_LANE; ++k) {
+                        const float x = __uint_as_float(
+                            __builtin_amdgcn_readlane(__float_as_uint(v[k]), l));
+                        s = s + x;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        const float nn = (float)sc->nf;  // finite_dists.len() as f32
+        if (PASS == 1) {
+            sc->mu = s / nn;
+        } else {
+            const float var = s / nn;
+            const float sd = sqrtf(var);
+            sc->sigma = sd;
+            sc->thr = sc->mu + std_mul * sd;
+        }
+    }
+}
+
+// keep[i] = mean[i] <= thr with the threshold read from device memory
+__global__ __launch_bounds__(256) void mask_dev_thr_kernel(const float *mean, size_t n,
+                                                           const StatsScalars *sc, uint8_t *keep,
+                                                           unsigned long long *count) {
+    const float thr = sc->has_finite ? sc->thr : -__builtin_inff();
+    unsigned local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const bool k = sc->has_finite && (mean[i] <= thr);
+        keep[i] = k ? 1 : 0;
+        local += k ? 1u : 0u;
+    }
+    if (!count) return;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, (unsigned long long)local);
+}
+
+}  // namespace pcrs
+
+using namespace pcrs;
+
+// Runs both passes; leaves {mu, thr, sigma, has_finite, nf} in *d_scalars (device).  No host sync.
+int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
+                          void *d_scalars, void *d_work, size_t work_bytes) {
+    const uint32_t nchunks = (uint32_t)((n + ST_CHUNK - 1) / ST_CHUNK);
+    const size_t need = pcrs_sor_stats_workspace(n);
+    if (work_bytes < need)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "stats workspace too small");
+    StatsScalars *sc = reinterpret_cast<StatsScalars *>(d_scalars);
+    char *w = reinterpret_cast<char *>(d_work);
+    double *csum = reinterpret_cast<double *>(w);
+    Composite *comp = reinterpret_cast<Composite *>(w + (size_t)nchunks * sizeof(double));
+    uint32_t *ccnt = reinterpret_cast<uint32_t *>(w + (size_t)nchunks * (sizeof(double) + sizeof(Composite)));
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
+    if (n == 0) return PCRS_OK;
+    const dim3 cgrid((nchunks + 3) / 4), cblock(256);
+    // pass 1: mean
+    hipLaunchKernelGGL(chunk_sums_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, nchunks);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, nchunks, sc, 1);
+    hipLaunchKernelGGL(chunk_composite_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, comp, nchunks);
+    hipLaunchKernelGGL(stats_walk_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, dmean, n, sc, comp, nchunks, std_mul);
+    // pass 2: variance
+    hipLaunchKernelGGL(chunk_sums_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, nchunks);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, nchunks, sc, 0);
+    hipLaunchKernelGGL(chunk_composite_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, comp, nchunks);
+    hipLaunchKernelGGL(stats_walk_kernel<2>, dim3(1), dim3(64), 0, ctx->stream, dmean, n, sc, comp, nchunks, std_mul);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+size_t pcrs_sor_stats_workspace(size_t n) {
+    const size_t nchunks = (n + ST_CHUNK - 1) / ST_CHUNK + 1;
+    return nchunks * (sizeof(double) + sizeof(Composite) + sizeof(uint32_t)) + 64;
+}
+
+size_t pcrs_sor_stats_scalars_bytes() { return sizeof(StatsScalars); }
+
+int pcrs_launch_mask_dev_thr(pcrs_ctx *ctx, const float *mean, size_t n, const void *d_scalars,
+                             uint8_t *keep, unsigned long long *d_count) {
+    if (d_count) PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(*d_count), ctx->stream));
+    if (n == 0) return PCRS_OK;
+    size_t blocks = (n + 255) / 256;
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(mask_dev_thr_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mean,
+                       n, reinterpret_cast<const StatsScalars *>(d_scalars), keep, d_count);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// host view of the device scalars
+void pcrs_sor_stats_decode(const void *host_copy, float *mu, float *thr, int *has_finite) {
+    const StatsScalars *sc = reinterpret_cast<const StatsScalars *>(host_copy);
+    if (mu) *mu = sc->mu;
+    if (thr) *thr = sc->thr;
+    if (has_finite) *has_finite = sc->has_finite ? 1 : 0;
+}

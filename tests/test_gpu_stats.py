@@ -1,0 +1,63 @@
+"""The device-side SOR statistics must reproduce the reference's left-to-right f32 sums
+(crates/filters/src/statistical_outlier.rs:43-62) bit for bit, for any data."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from pointclouds_rs.dist import HipEngine
+
+    return HipEngine(0)
+
+
+def cases():
+    rng = np.random.default_rng(5)
+    out = {}
+    for n in (1, 2, 63, 255, 256, 257, 1000, 5000, 70000, 1_000_000):
+        out[f"uniform_{n}"] = rng.uniform(0.2, 3.0, n).astype(F)
+    m = rng.uniform(0.5, 2.0, 300000).astype(F)
+    m[::1000] = 5000.0  # heavy outliers: binade jumps in the middle of the stream
+    out["outliers"] = m
+    m = rng.uniform(0.5, 2.0, 100000).astype(F)
+    m[::7] = np.inf
+    m[3::11] = np.nan
+    out["nonfinite"] = m
+    out["all_inf"] = np.full(1000, np.inf, dtype=F)
+    out["dyadic_ties"] = (rng.integers(0, 64, 200000) * 0.0625).astype(F)  # exact rounding ties
+    out["constant_half"] = np.full(300000, 0.5, dtype=F)
+    out["zeros_then_ones"] = np.concatenate([np.zeros(5000, F), np.ones(50000, F)])
+    out["tiny"] = rng.uniform(1e-36, 1e-33, 20000).astype(F)  # below the scanned binades
+    out["huge_range"] = np.exp(rng.uniform(-60, 60, 100000)).astype(F)
+    out["descending"] = np.sort(rng.uniform(0.0, 10.0, 200000).astype(F))[::-1].copy()
+    out["lognormal"] = rng.lognormal(0.0, 2.0, 400000).astype(F)
+    return out
+
+
+@pytest.mark.parametrize("name", list(cases()))
+@pytest.mark.parametrize("mul", [0.0, 1.0, 2.5])
+def test_threshold_bit_exact(engine, oracle, name, mul):
+    m = cases()[name]
+    ok_ref, thr_ref, mu_ref, sd_ref = oracle.sor_threshold(m, mul)
+    d = engine.from_numpy(m)
+    thr, ok = engine.threshold(d, mul)
+    assert ok == ok_ref
+    if ok:
+        assert F(thr).view(np.uint32) == F(thr_ref).view(np.uint32), (name, thr, thr_ref)
+    else:
+        assert np.isnan(thr)
+
+
+def test_mask_matches(engine, oracle):
+    m = cases()["outliers"]
+    _, thr_ref, _, _ = oracle.sor_threshold(m, 1.0)
+    d = engine.from_numpy(m)
+    thr, ok = engine.threshold(d, 1.0)
+    keep = engine.empty(len(m), "uint8")
+    n_keep = engine.mask(d, thr, keep)
+    ref = m <= F(thr_ref)
+    assert n_keep == int(ref.sum())
+    assert np.array_equal(keep.cpu().numpy().astype(bool), ref)

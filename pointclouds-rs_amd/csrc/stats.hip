@@ -206,7 +206,11 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
     if (lane == 0) comp[chunk] = f;
 }
 
-// One wave walks the chunks in order carrying the exact f32 running sum.
+// One wave walks the chunks in order carrying the exact f32 running sum.  64 chunk composites
+// are taken at a time: an inclusive scan of function composition over the lanes gives the state
+// after every chunk of the batch at once, the first chunk that leaves the binade (or was built for
+// another one) is found with a ballot, summed element by element with real f32 adds, and the
+// scan restarts behind it.
 template <int PASS>
 __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_t n,
                                                         StatsScalars *sc, const Composite *comp,
@@ -221,27 +225,51 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
         mine.pad = 0;
         if (base + lane < nchunks) mine = comp[base + lane];
         const uint32_t lim = min(64u, nchunks - base);
-        for (uint32_t j = 0; j < lim; ++j) {
-            const uint32_t a0 = __builtin_amdgcn_readlane(mine.a0, j);
-            const uint32_t a1 = __builtin_amdgcn_readlane(mine.a1, j);
-            const int e = (int)__builtin_amdgcn_readlane((uint32_t)mine.e, j);
+        uint32_t pos = 0;
+        while (pos < lim) {
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
-            bool done = false;
-            if (e != ST_NO_BINADE && binade_of(__uint_as_float(bits)) == e) {
-                const uint32_t S = (bits & 0x7FFFFFu) | 0x800000u;
-                const uint32_t S2 = S + ((S & 1u) ? a1 : a0);
-                if (S2 < (1u << 24)) {
-                    s = __uint_as_float((bits & 0xFF800000u) | (S2 & 0x7FFFFFu));
-                    done = true;
-                }
+            const int e_now = binade_of(__uint_as_float(bits));
+            const uint32_t S = (bits & 0x7FFFFFu) | 0x800000u;
+            // composites of the chunks already consumed act as the identity; unusable ones
+            // saturate so that everything from them on reads as "left the binade"
+            Composite f;
+            f.e = e_now;
+            f.pad = 0;
+            if ((uint32_t)lane < pos) {
+                f.a0 = f.a1 = 0;
+            } else if (e_now != ST_NO_BINADE && mine.e == e_now && (uint32_t)lane < lim) {
+                f.a0 = mine.a0;
+                f.a1 = mine.a1;
+            } else {
+                f.a0 = f.a1 = ST_SAT;
             }
-            if (!done) {
+            for (int off = 1; off < 64; off <<= 1) {
+                Composite g;
+                g.a0 = __shfl_up(f.a0, off, 64);
+                g.a1 = __shfl_up(f.a1, off, 64);
+                g.e = e_now;
+                g.pad = 0;
+                if (lane >= off) f = compose(g, f);
+            }
+            const uint32_t S_after = S + ((S & 1u) ? f.a1 : f.a0);
+            const bool ok = S_after < (1u << 24);
+            unsigned long long bad = ~__ballot(ok);
+            bad &= ~((1ull << pos) - 1ull);  // lanes before pos are not part of the question
+            if (lim < 64u) bad &= (1ull << lim) - 1ull;
+            const uint32_t first_bad = bad ? (uint32_t)__builtin_ctzll(bad) : lim;
+            if (first_bad > pos) {
+                const uint32_t Sj = __builtin_amdgcn_readlane(S_after, first_bad - 1);
+                s = __uint_as_float((bits & 0xFF800000u) | (Sj & 0x7FFFFFu));
+            }
+            if (first_bad < lim) {
                 // element-by-element f32 adds over this chunk (lane-major element order)
                 float v[ST_PER_LANE];
 #pragma unroll
                 for (int k = 0; k < ST_PER_LANE; ++k) {
                     bool fin;
-                    v[k] = stat_element<PASS>(mean, n, (size_t)(base + j) * ST_CHUNK + lane * ST_PER_LANE + k, mu, &fin);
+                    v[k] = stat_element<PASS>(
+                        mean, n, (size_t)(base + first_bad) * ST_CHUNK + lane * ST_PER_LANE + k, mu,
+                        &fin);
                 }
                 for (int l = 0; l < 64; ++l) {
 #pragma unroll
@@ -252,6 +280,7 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                     }
                 }
             }
+            pos = first_bad + 1;
         }
     }
     if (lane == 0) {

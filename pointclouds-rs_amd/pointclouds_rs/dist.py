@@ -166,9 +166,18 @@ class Collectives:
         """Concatenation over ranks of 1-D tensors whose lengths are `counts` (known everywhere)."""
         if self.world == 1:
             return local
-        outs = [torch.empty(c, dtype=local.dtype, device=local.device) for c in counts]
-        self.dist.all_gather(outs, local.contiguous())
-        return torch.cat(outs)
+        maxc = max(counts)
+        local = local.contiguous()
+        if min(counts) == maxc:  # equal shards: one collective straight into the result
+            out = torch.empty(self.world * maxc, dtype=local.dtype, device=local.device)
+            self.dist.all_gather_into_tensor(out, local)
+            return out
+        # uneven shards: the collective needs equal sizes, so pad to the largest shard
+        padded = torch.zeros(maxc, dtype=local.dtype, device=local.device)
+        padded[: local.numel()] = local
+        out = torch.empty(self.world * maxc, dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(out, padded)
+        return torch.cat([out[r * maxc: r * maxc + counts[r]] for r in range(self.world)])
 
     def all_reduce_sum_f64(self, torch, arr, device):
         """Sums a small float64 NumPy vector over ranks (rank-order independent result)."""

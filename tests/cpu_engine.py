@@ -1,0 +1,86 @@
+"""CPU stand-in for pointclouds_rs.dist.HipEngine, backed by the oracle.  TEST INFRASTRUCTURE:
+it lets the rank/shard/collective logic of pointclouds_rs.dist run under gloo without a GPU."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from pointclouds_rs import _ffi
+
+
+class CpuEngine:
+    def __init__(self, oracle):
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self.o = oracle
+        self.lib = _ffi.load_library()  # pcrs_icp_solve / pcrs_compose are pure host math
+
+    def empty(self, n, dtype="float32"):
+        return torch.empty(n, dtype=getattr(torch, dtype))
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def build_index(self, x, y, z, k_hint=0, algo=0):
+        return (x.numpy(), y.numpy(), z.numpy())
+
+    def destroy_index(self, h):
+        pass
+
+    def index_stats(self, h):
+        return [0, 0, 0]
+
+    def sor_normals_range(self, index, q_begin, q_count, k_sor, k_nrm, viewpoint, mean, nx, ny, nz):
+        x, y, z = index
+        sl = slice(q_begin, q_begin + q_count)
+        if mean is not None:
+            mean.copy_(torch.from_numpy(self.o.sor_mean_dist(x, y, z, k_sor, algo=1)[sl].copy()))
+        if nx is not None:
+            n = self.o.normals(x, y, z, k_nrm, viewpoint, algo=1)
+            for dst, src in zip((nx, ny, nz), n):
+                dst.copy_(torch.from_numpy(src[sl].copy()))
+
+    def threshold(self, mean_full, std_mul):
+        ok, thr, _, _ = self.o.sor_threshold(mean_full.numpy(), std_mul)
+        return (thr if ok else float("nan")), ok
+
+    def mask(self, mean, thr, keep, want_count=True):
+        k = mean.numpy() <= np.float32(thr)
+        keep.copy_(torch.from_numpy(k.astype(np.uint8)))
+        return int(k.sum())
+
+    # ---- ICP
+    def icp_create(self, src, tgt, normals):
+        return dict(src=[c.numpy().copy() for c in src], tgt=[c.numpy() for c in tgt],
+                    tn=[c.numpy() for c in normals] if normals is not None else None, cur=None)
+
+    def icp_destroy(self, h):
+        pass
+
+    def icp_reset(self, h):
+        h["cur"] = list(self.o.apply_transform(*h["src"], np.eye(3), (0, 0, 0)))
+
+    def icp_accumulate(self, h, mode, max_d):
+        st = self.o.icp_step(h["cur"], h["tgt"], h["tn"], max_d, algo=1)
+        s = np.zeros(_ffi.ICP_NSUMS)
+        s[0], s[1] = st["n_corr"], st["sum_d2"]
+        if mode == _ffi.ICP_POINT_TO_PLANE:
+            ata = st["plane"][:36].reshape(6, 6)
+            s[2:23] = [ata[r, c] for r in range(6) for c in range(r, 6)]
+            s[23:29] = st["plane"][36:]
+        else:
+            s[2:17] = st["point"]
+        return s
+
+    def icp_solve(self, mode, sums):
+        rot, t = (C.c_float * 9)(), (C.c_float * 3)()
+        assert self.lib.pcrs_icp_solve(mode, sums.ctypes.data_as(_ffi.c_f64_p), rot, t) == 0
+        return rot, t
+
+    def icp_apply(self, h, rot, t):
+        h["cur"] = list(self.o.apply_transform(*h["cur"], np.array(rot, np.float32).reshape(3, 3), list(t)))
+
+    def compose(self, ra, ta, rb, tb):
+        ro, to = (C.c_float * 9)(), (C.c_float * 3)()
+        self.lib.pcrs_compose(ra, ta, rb, tb, ro, to)
+        return ro, to

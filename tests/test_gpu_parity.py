@@ -277,3 +277,42 @@ def test_python_surface_end_to_end(hip):
     assert res.converged and res.rmse < 0.1
     moved = pc.apply_transform(pc.PointCloud.from_numpy(sq), np.eye(3), [1, 2, 3])
     assert np.array_equal(moved.to_numpy(), sq + np.array([1, 2, 3], dtype=F))
+
+
+def test_query_subrange_equals_full(oracle):
+    """Query sharding: a sub-range [q_begin, q_begin + q_count) of the indexed cloud (the
+    multi-GPU path) must give exactly the rows of the full-range result."""
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine(0)
+    x, y, z = gen.degenerate_cloud(300, 7)
+    ux, uy, uz = gen.uniform_cloud(30000, 11)
+    x, y, z = np.concatenate([x, ux]), np.concatenate([y, uy]), np.concatenate([z, uz])
+    n = len(x)
+    cols = [eng.from_numpy(c) for c in (x, y, z)]
+    rmean = oracle.sor_mean_dist(x, y, z, 16, algo=1)
+    rn = oracle.normals(x, y, z, 16, (1.0, 2.0, 3.0), algo=1)
+    for algo in (1, 2):
+        ix = eng.build_index(*cols, 17, algo)
+        for b, c in ((0, n), (0, 1), (123, 7001), (n - 5000, 5000), (17, 0)):
+            mean = eng.empty(c); nx = eng.empty(c); ny = eng.empty(c); nz = eng.empty(c)
+            eng.sor_normals_range(ix, b, c, 16, 16, (1.0, 2.0, 3.0), mean, nx, ny, nz)
+            eng.torch.cuda.synchronize()
+            assert np.array_equal(mean.cpu().numpy().view(np.uint32), rmean[b:b + c].view(np.uint32))
+            for got, ref in zip((nx, ny, nz), rn):
+                g, r = got.cpu().numpy(), ref[b:b + c]
+                assert np.abs(g.astype(np.float64) - r).max(initial=0.0) <= 1e-5
+        eng.destroy_index(ix)
+
+
+def test_search_stage_statistics():
+    """The retry stages must actually be exercised by clouds with sparse outliers."""
+    from pointclouds_rs import hip
+
+    x, y, z = gen.kitti_scene(42)
+    ix = hip.Index(x, y, z, k_hint=17, algo=2)
+    ix.knn(x, y, z, 17)
+    st = ix.last_stats()
+    ix.close()
+    assert st["grid_tile"] + st["grid_ring"] + st["brute"] == len(x)
+    assert st["grid_tile"] > 0.9 * len(x) and st["grid_ring"] > 0

@@ -249,22 +249,26 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
             const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
             const uint32_t s0 = a.cell_start[row + x0];
             const uint32_t s1 = a.cell_start[row + x1 + 1];
-            // two loads in flight per iteration: the walk is latency-sensitive
+            // four loads in flight per iteration: the walk is latency-bound, not VALU-bound
             uint32_t s = s0;
-            for (; s + 1 < s1; s += 2) {
+            for (; s + 3 < s1; s += 4) {
                 const float4 p0 = a.spts[s];
                 const float4 p1 = a.spts[s + 1];
+                const float4 p2 = a.spts[s + 2];
+                const float4 p3 = a.spts[s + 3];
                 f(p0, s);
                 f(p1, s + 1);
+                f(p2, s + 2);
+                f(p3, s + 3);
             }
-            if (s < s1) f(a.spts[s], s);
+            for (; s < s1; ++s) f(a.spts[s], s);
         }
     }
 }
 
 template <int K, bool COLLECT>
 __global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut out) {
-    constexpr int CAP = K + 7;  // per-lane candidate list for pass 2
+    constexpr int CAP = K + 3;  // per-lane candidate list for pass 2 (ties beyond it retry per wave)
     __shared__ uint32_t lst[COLLECT ? CAP : 1][GB_THREADS];
 
     uint32_t total = a.nq;

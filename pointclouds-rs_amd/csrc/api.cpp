@@ -54,6 +54,50 @@ int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out) {
     return PCRS_OK;
 }
 
+hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap) {
+    // best fit among the free buffers that are not wastefully large
+    size_t best = ctx->pool.size();
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+        const size_t c = ctx->pool[i].bytes;
+        if (c >= bytes && c <= 2 * bytes + (1u << 20) &&
+            (best == ctx->pool.size() || c < ctx->pool[best].bytes))
+            best = i;
+    }
+    if (best != ctx->pool.size()) {
+        *p = ctx->pool[best].p;
+        *cap = ctx->pool[best].bytes;
+        ctx->pool[best] = ctx->pool.back();
+        ctx->pool.pop_back();
+        return hipSuccess;
+    }
+    // round up so that slightly different sizes of the next call still fit
+    size_t want = bytes < (1u << 20) ? ((bytes + 65535) & ~(size_t)65535)
+                                     : ((bytes + bytes / 8 + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1));
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess && !ctx->pool.empty()) {
+        // give the pooled memory back and retry once
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto &pe : ctx->pool) (void)hipFree(pe.p);
+        ctx->pool.clear();
+        e = hipMalloc(p, want);
+    }
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+void pcrs_pool_release(pcrs_ctx *ctx, void *p, size_t cap) {
+    if (ctx->pool.size() >= 64) {  // keep the pool bounded: drop the largest idle buffer
+        size_t big = 0;
+        for (size_t i = 1; i < ctx->pool.size(); ++i)
+            if (ctx->pool[i].bytes > ctx->pool[big].bytes) big = i;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->pool[big].p);
+        ctx->pool[big] = ctx->pool.back();
+        ctx->pool.pop_back();
+    }
+    ctx->pool.push_back({p, cap});
+}
+
 void pcrs_timing_begin(pcrs_ctx *ctx) {
     if (!ctx->timing) return;
     if (ctx->timing_depth++ > 0) return;
@@ -170,6 +214,7 @@ void pcrs_ctx_destroy(pcrs_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &pe : ctx->pool) (void)hipFree(pe.p);
     for (hipEvent_t e : ctx->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_stop) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -264,10 +309,9 @@ int pcrs_index_build(pcrs_ctx *ctx, const float *x, const float *y, const float 
 
 void pcrs_index_destroy(pcrs_index *index) {
     if (!index) return;
-    if (index->ctx) {
-        (void)hipSetDevice(index->ctx->device);
-        (void)hipStreamSynchronize(index->ctx->stream);
-    }
+    // Grid buffers return to the context's pool (stream-ordered reuse, no wait); buffers uploaded
+    // from host memory are hipFree'd, which waits for the device by itself.
+    if (index->ctx) (void)hipSetDevice(index->ctx->device);
     delete index;
 }
 

@@ -98,30 +98,25 @@ __device__ __forceinline__ uint32_t cell_index(const GridGeom &g, float x, float
     return ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
 }
 
-// cell id per point (PCRS_NO_INDEX for non-finite points) and the cell histogram
+// cell id per point (PCRS_NO_INDEX for non-finite points), the cell histogram and the number of
+// non-empty cells (the point that finds a cell empty counts it)
 __global__ __launch_bounds__(GB_THREADS) void cell_count_kernel(const float *x, const float *y,
                                                                 const float *z, uint32_t m,
                                                                 GridGeom g, uint32_t *cell_id,
-                                                                uint32_t *counts) {
+                                                                uint32_t *counts,
+                                                                uint32_t *nonempty) {
+    unsigned opened = 0;
     for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < m; i += gridDim.x * GB_THREADS) {
         const float px = x[i], py = y[i], pz = z[i];
         uint32_t c = PCRS_NO_INDEX;
         if (finite3(px, py, pz)) {
             c = cell_index(g, px, py, pz);
-            atomicAdd(&counts[c], 1u);
+            opened += (atomicAdd(&counts[c], 1u) == 0u) ? 1u : 0u;
         }
-        if (cell_id) cell_id[i] = c;
+        cell_id[i] = c;
     }
-}
-
-__global__ __launch_bounds__(GB_THREADS) void nonempty_kernel(const uint32_t *counts,
-                                                              uint32_t ncell, uint32_t *out) {
-    unsigned local = 0;
-    for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < ncell;
-         i += gridDim.x * GB_THREADS)
-        local += counts[i] ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+    for (int off = 32; off > 0; off >>= 1) opened += __shfl_down(opened, off, 64);
+    if ((threadIdx.x & 63) == 0 && opened) atomicAdd(nonempty, opened);
 }
 
 // Exclusive scan of counts[0..n) in three launches: per-block scan of 1024 elements, scan of the
@@ -667,19 +662,6 @@ unsigned grid_for(pcrs_ctx *ctx, size_t n, int threads) {
     return (unsigned)blocks;
 }
 
-int exclusive_scan(pcrs_ctx *ctx, uint32_t *data, uint32_t n, DevBuf &sums) {
-    const uint32_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    PCRS_HIP_CHECK(ctx, sums.alloc(((size_t)nblocks + 1) * sizeof(uint32_t)));
-    hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream, data, n,
-                       sums.as<uint32_t>());
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums.as<uint32_t>(),
-                       nblocks, data + n);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream, data, n,
-                       sums.as<uint32_t>());
-    PCRS_HIP_CHECK(ctx, hipGetLastError());
-    return PCRS_OK;
-}
-
 // Points per cell the grid aims for: the 27-cell cube then holds ~27 P candidates and the ball
 // of radius one cell ~4.2 P >= 2 K points, so the first stage certifies almost every query.
 double target_occupancy(uint32_t k_hint) {
@@ -738,16 +720,19 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
     // 1. bounding box of the finite points
     const unsigned nb = grid_for(ctx, m, GB_THREADS);
     DevBuf partials;
-    PCRS_HIP_CHECK(ctx, partials.alloc(nb * sizeof(BBoxPartial)));
+    PCRS_HIP_CHECK(ctx, partials.alloc(ctx, nb * sizeof(BBoxPartial)));
     hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
                        ix->z, m, partials.as<BBoxPartial>());
-    std::vector<BBoxPartial> hp(nb);
-    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hp.data(), partials.p, nb * sizeof(BBoxPartial),
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, nb * sizeof(BBoxPartial) + 64, &pin));
+    BBoxPartial *hp = reinterpret_cast<BBoxPartial *>(pin);
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hp, partials.p, nb * sizeof(BBoxPartial),
                                        hipMemcpyDeviceToHost, ctx->stream));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     size_t nvalid = 0;
-    for (const BBoxPartial &p : hp) {
+    for (unsigned b = 0; b < nb; ++b) {
+        const BBoxPartial &p = hp[b];
         nvalid += p.nvalid;
         for (int a = 0; a < 3; ++a) {
             if (p.lo[a] < lo[a]) lo[a] = p.lo[a];
@@ -774,28 +759,25 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
     GridGeom g{};
     uint32_t ncell = 0;
     DevBuf counts, cell_id;
-    PCRS_HIP_CHECK(ctx, cell_id.alloc((size_t)m * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
+    // sized for the largest grid the budget allows: no reallocation between attempts
+    PCRS_HIP_CHECK(ctx, counts.alloc(ctx, ((size_t)max_cells + 8) * sizeof(uint32_t)));
+    uint32_t *h_nonempty = reinterpret_cast<uint32_t *>(pin);
     for (int attempt = 0;; ++attempt) {
         double used = cell;
         make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
         cell = used;
-        if (counts.bytes < ((size_t)ncell + 2) * sizeof(uint32_t)) {
-            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            PCRS_HIP_CHECK(ctx, counts.alloc(((size_t)ncell + 2) * sizeof(uint32_t)));
-        }
         PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
                                            ctx->stream));
-        hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
-                           ix->y, ix->z, m, g, cell_id.as<uint32_t>(), counts.as<uint32_t>());
-        if (attempt == 3) break;
         uint32_t *d_nonempty = counts.as<uint32_t>() + ncell + 1;
-        hipLaunchKernelGGL(nonempty_kernel, dim3(grid_for(ctx, ncell, GB_THREADS)),
-                           dim3(GB_THREADS), 0, ctx->stream, counts.as<uint32_t>(), ncell,
+        hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
+                           ix->y, ix->z, m, g, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
                            d_nonempty);
-        uint32_t nonempty = 0;
-        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(&nonempty, d_nonempty, sizeof(uint32_t),
+        if (attempt == 3) break;
+        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_nonempty, d_nonempty, sizeof(uint32_t),
                                            hipMemcpyDeviceToHost, ctx->stream));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t nonempty = *h_nonempty;
         const double occ = (double)nvalid / (double)(nonempty ? nonempty : 1);
         if (occ <= 1.6 * P) break;
         // occupied volume ~ nonempty * cell^3: re-aim at P points per occupied cell.  A surface
@@ -812,24 +794,32 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
         cell = next;
     }
 
-    // 3. scan the histogram into slot ranges and scatter the points
+    // 3. scan the histogram into slot ranges and scatter the points.  All buffers come from the
+    //    context's pool, so the temporaries are released without waiting for the stream.
     DevBuf scan_sums, fill;
-    PCRS_TRY(exclusive_scan(ctx, counts.as<uint32_t>(), ncell, scan_sums));
-    PCRS_HIP_CHECK(ctx, fill.alloc((size_t)ncell * sizeof(uint32_t)));
+    const uint32_t nblocks = (ncell + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    PCRS_HIP_CHECK(ctx, scan_sums.alloc(ctx, ((size_t)nblocks + 1) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream,
+                       counts.as<uint32_t>(), ncell, scan_sums.as<uint32_t>());
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       scan_sums.as<uint32_t>(), nblocks, counts.as<uint32_t>() + ncell);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream,
+                       counts.as<uint32_t>(), ncell, scan_sums.as<uint32_t>());
+    PCRS_HIP_CHECK(ctx, fill.alloc(ctx, (size_t)ncell * sizeof(uint32_t)));
     PCRS_HIP_CHECK(ctx, hipMemcpyAsync(fill.p, counts.p, (size_t)ncell * sizeof(uint32_t),
                                        hipMemcpyDeviceToDevice, ctx->stream));
-    PCRS_HIP_CHECK(ctx, ix->spts.alloc(nvalid * sizeof(float4)));
+    PCRS_HIP_CHECK(ctx, ix->spts.alloc(ctx, nvalid * sizeof(float4)));
     hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
                        ix->z, m, cell_id.as<uint32_t>(), fill.as<uint32_t>(),
                        ix->spts.as<float4>());
     PCRS_HIP_CHECK(ctx, hipGetLastError());
-    // the temporaries above are freed on return: wait for the kernels that use them
-    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ix->cell_start.release();
     ix->cell_start.p = counts.p;  // take ownership of the scanned histogram
     ix->cell_start.bytes = counts.bytes;
+    ix->cell_start.owner = counts.owner;
     counts.p = nullptr;
     counts.bytes = 0;
+    counts.owner = nullptr;
     ix->g = g;
     ix->ncell = ncell;
     ix->algo = PCRS_ALGO_GRID;
@@ -858,8 +848,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
     const size_t list_elems = (size_t)nq + 64;
     const size_t need = (2 * list_elems + 64) * sizeof(uint32_t);
     if (ix->fail_lists.bytes < need) {
-        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(need));
+        PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
     }
     uint32_t *listA = ix->fail_lists.as<uint32_t>();
     uint32_t *listB = listA + list_elems;

@@ -34,7 +34,17 @@ struct pcrs_ctx {
     std::vector<hipEvent_t> ev_start, ev_stop;  // one pair per bracketed launch
     size_t ev_used = 0;
     int timing_depth = 0;  // nested brackets collapse into the outermost one
+    // Free device buffers kept for reuse.  Everything a context does runs on its one stream, so
+    // a buffer released by one operation can be handed to the next without synchronising.
+    struct PoolEntry {
+        void *p;
+        size_t bytes;
+    };
+    std::vector<PoolEntry> pool;
 };
+
+hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap);
+void pcrs_pool_release(pcrs_ctx *ctx, void *p, size_t cap);
 
 // Brackets one launch of the dominant (neighbour-search) kernel with HIP events on the context's
 // stream when timing is enabled; no-ops otherwise.
@@ -61,21 +71,35 @@ int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out);
                                 __FILE__, __LINE__);                                           \
     } while (0)
 
-// Simple owning device buffer.
+// Owning device buffer; pooled when allocated through a context.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    hipError_t alloc(size_t b) {
+    pcrs_ctx *owner = nullptr;
+    hipError_t alloc(size_t b) {  // plain hipMalloc
         release();
         if (b == 0) b = 16;
         hipError_t e = hipMalloc(&p, b);
         if (e == hipSuccess) bytes = b;
         return e;
     }
+    hipError_t alloc(pcrs_ctx *ctx, size_t b) {  // from the context's pool
+        release();
+        if (b == 0) b = 16;
+        hipError_t e = pcrs_pool_alloc(ctx, b, &p, &bytes);
+        if (e == hipSuccess) owner = ctx;
+        return e;
+    }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (owner)
+                pcrs_pool_release(owner, p, bytes);
+            else
+                (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
+        owner = nullptr;
     }
     template <class T>
     T *as() const {

@@ -222,7 +222,8 @@ struct CellArgs {
     uint32_t q_begin, q_len;
     const uint32_t *qlist;
     const uint32_t *qcount;
-    int R;                  // cube half-width in cells
+    int R;                  // cube half-width in cells (per-lane kernels)
+    int wave_radii[3];      // cube half-widths the wave-per-query kernel tries in turn
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
     uint32_t kcert;         // neighbours that must be certified (<= K)
@@ -413,7 +414,6 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t total = *a.qcount;
     const GridGeom &g = a.g;
-    const int R = a.R;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (uint32_t pos = blockIdx.x * WAVES + w; pos < total; pos += gridDim.x * WAVES) {
@@ -423,63 +423,71 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
         const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
         const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
-        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
-        const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
-        const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
-
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
         float D[K];
+        bool certified = false;
+        // larger and larger cubes until the K-th distance is certified (the wave is uniform
+        // in the query, so the escalation costs no divergence)
+#pragma unroll 1
+        for (int ri = 0; ri < 3 && !certified; ++ri) {
+            const int R = a.wave_radii[ri];
+            x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+            y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+            z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
 #pragma unroll
-        for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
-        for (int zz = z0; zz <= z1; ++zz)
-            for (int yy = y0; yy <= y1; ++yy) {
-                const uint32_t row =
-                    ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
-                const uint32_t s0 = a.cell_start[row + x0], s1 = a.cell_start[row + x1 + 1];
-                for (uint32_t s = s0 + lane; s < s1; s += 64) {
-                    const float4 p = a.spts[s];
-                    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+            for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
+            for (int zz = z0; zz <= z1; ++zz)
+                for (int yy = y0; yy <= y1; ++yy) {
+                    const uint32_t row =
+                        ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                    const uint32_t s0 = a.cell_start[row + x0], s1 = a.cell_start[row + x1 + 1];
+                    for (uint32_t s = s0 + lane; s < s1; s += 64) {
+                        const float4 p = a.spts[s];
+                        const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+#pragma unroll
+                        for (int t = K - 1; t > 0; --t)
+                            D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
+                        D[0] = fminf(D[0], d2);
+                    }
+                }
+            // butterfly merge of the 64 per-lane lists
+#pragma unroll 1
+            for (int r = 1; r < 64; r <<= 1) {
+                float T[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) T[i] = D[i];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float v = __shfl_xor(T[j], r, 64);
 #pragma unroll
                     for (int t = K - 1; t > 0; --t)
-                        D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
-                    D[0] = fminf(D[0], d2);
+                        D[t] = __builtin_amdgcn_fmed3f(v, D[t - 1], D[t]);
+                    D[0] = fminf(D[0], v);
                 }
             }
-        // butterfly merge of the 64 per-lane lists
-#pragma unroll 1
-        for (int r = 1; r < 64; r <<= 1) {
-            float T[K];
+            const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
+                               (z0 == 0) && (z1 == g.nz - 1);
+            certified = whole;
+            float tau_cert = __builtin_inff();
 #pragma unroll
-            for (int i = 0; i < K; ++i) T[i] = D[i];
+            for (int i = 0; i < K; ++i)
+                if ((uint32_t)i == a.kcert - 1) tau_cert = D[i];
+            if (!whole) {
+                float margin = __builtin_inff();
+                const float u[3] = {ux, uy, uz};
+                const int c[3] = {cx, cy, cz};
+                const int n[3] = {g.nx, g.ny, g.nz};
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const float v = __shfl_xor(T[j], r, 64);
-#pragma unroll
-                for (int t = K - 1; t > 0; --t) D[t] = __builtin_amdgcn_fmed3f(v, D[t - 1], D[t]);
-                D[0] = fminf(D[0], v);
+                for (int ax = 0; ax < 3; ++ax) {
+                    if (c[ax] - R > 0)
+                        margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                    if (c[ax] + R < n[ax] - 1)
+                        margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+                }
+                const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+                const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
+                certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
             }
-        }
-
-        const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
-                           (z0 == 0) && (z1 == g.nz - 1);
-        bool certified = whole;
-        float tau_cert = __builtin_inff();
-#pragma unroll
-        for (int i = 0; i < K; ++i)
-            if ((uint32_t)i == a.kcert - 1) tau_cert = D[i];
-        if (!whole) {
-            float margin = __builtin_inff();
-            const float u[3] = {ux, uy, uz};
-            const int c[3] = {cx, cy, cz};
-            const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                if (c[ax] + R < n[ax] - 1)
-                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-            }
-            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
-            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
-            certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
         }
         bool failed = !certified;
 
@@ -941,18 +949,17 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
 #undef PCRS_WAVE_CALL
     };
     const unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);
-    const int radii[3] = {2, 4, 8};
-    uint32_t *src = listA, *dst = listB;
-    for (int st = 0; st < 3; ++st) {
-        a.qmode = 2;
-        a.R = radii[st];
-        a.qlist = src;
-        a.qcount = &counters[st];
-        a.fail_list = dst;
-        a.fail_count = &counters[st + 1];
-        launch_wave(retry_blocks);
-        std::swap(src, dst);
-    }
+    // one launch tries the cube half-widths 2, 4, 8 in turn for each failed query
+    a.wave_radii[0] = 2;
+    a.wave_radii[1] = 4;
+    a.wave_radii[2] = 8;
+    a.qmode = 2;
+    a.qlist = listA;
+    a.qcount = &counters[0];
+    a.fail_list = listB;
+    a.fail_count = &counters[3];
+    launch_wave(retry_blocks);
+    uint32_t *src = listB;
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     // stage 4: brute force over what is left
     const int rc_bf = pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, src,

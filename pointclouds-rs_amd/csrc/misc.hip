@@ -174,13 +174,21 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
     }
 }
 
-__global__ __launch_bounds__(64) void icp_final_kernel(const double *partials, uint32_t nblocks,
-                                                       double *sums) {
-    const int i = threadIdx.x;
-    if (i >= PCRS_ICP_NSUMS) return;
+// Stage 2: 32 groups of threads fold the block partials (group g takes blocks g, g+32, ... in
+// order), then 32 threads fold the groups in order: a fixed summation tree, a few microseconds.
+__global__ __launch_bounds__(1024) void icp_final_kernel(const double *partials, uint32_t nblocks,
+                                                         double *sums) {
+    __shared__ double grp[32][PCRS_ICP_NSUMS + 1];
+    const int i = threadIdx.x & 31, gidx = threadIdx.x >> 5;
     double v = 0.0;
-    for (uint32_t b = 0; b < nblocks; ++b) v += partials[(size_t)b * PCRS_ICP_NSUMS + i];
-    sums[i] = v;
+    for (uint32_t b = gidx; b < nblocks; b += 32) v += partials[(size_t)b * PCRS_ICP_NSUMS + i];
+    grp[gidx][i] = v;
+    __syncthreads();
+    if (threadIdx.x < PCRS_ICP_NSUMS) {
+        double t = 0.0;
+        for (int q = 0; q < 32; ++q) t += grp[q][threadIdx.x];
+        sums[threadIdx.x] = t;
+    }
 }
 
 }  // namespace pcrs
@@ -246,7 +254,7 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
         return PCRS_OK;
     }
     size_t blocks = (n + ICP_THREADS - 1) / ICP_THREADS;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     void *scratch = nullptr;
     int rc = pcrs_ctx_scratch(ctx, blocks * PCRS_ICP_NSUMS * sizeof(double), &scratch);
     if (rc != PCRS_OK) return rc;
@@ -259,7 +267,7 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
         hipLaunchKernelGGL(icp_partial_kernel<PCRS_ICP_POINT_TO_POINT>, dim3((unsigned)blocks),
                            dim3(ICP_THREADS), 0, ctx->stream, cx, cy, cz, (uint32_t)n, tx, ty, tz,
                            tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials);
-    hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partials,
+    hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, partials,
                        (uint32_t)blocks, d_sums);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;

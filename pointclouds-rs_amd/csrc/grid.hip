@@ -262,10 +262,22 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
     }
 }
 
+#ifndef PCRS_WPE
+#define PCRS_WPE 1
+#endif
+// Waves per SIMD the register allocator must leave room for: the walk is latency-bound, so
+// occupancy is worth more than a few spilled or rematerialised values.
+constexpr int cell_min_waves(int k, bool collect) {
+    return k <= 17 ? PCRS_WPE : 1;
+}
+
 template <int K, bool COLLECT>
-__global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut out) {
-    constexpr int CAP = K + 3;  // per-lane candidate list for pass 2 (ties beyond it retry per wave)
-    __shared__ uint32_t lst[COLLECT ? CAP : 1][GB_THREADS];
+__global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(cell_min_waves(K, COLLECT))))
+void knn_cell_kernel(CellArgs a, KnnOut out) {
+    // per-lane neighbour list for pass 2; ties at the K-th distance beyond it retry per wave
+    constexpr int CAP = K + 3 < 64 ? K + 3 : 64;
+    __shared__ uint32_t lst[COLLECT ? CAP : 1][GB_THREADS];  // slots of the hits, walk order
+    __shared__ uint8_t ord[COLLECT ? CAP : 1][GB_THREADS];   // ord[r] = list position of rank r
 
     uint32_t total = a.nq;
     if (a.qmode >= 2) total = *a.qcount;
@@ -292,7 +304,8 @@ __global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut
         const bool qvalid = finite3(qx, qy, qz);
         if (!qvalid) {  // no neighbours: the consumers write their defaults
             uint64_t none[1] = {PCRS_EMPTY_KEY};
-            consume(RegNbrs<1>(none, a.rx, a.ry, a.rz), 0u, false, (size_t)qi, qx, qy, qz, out);
+            consume<true>(RegNbrs<1>(none, a.rx, a.ry, a.rz), 0u, false, (size_t)qi, qx, qy, qz,
+                          out);
             continue;
         }
         const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
@@ -363,38 +376,82 @@ __global__ __launch_bounds__(GB_THREADS) void knn_cell_kernel(CellArgs a, KnnOut
         }
 
         if constexpr (COLLECT) {
-            // ---- pass 2: identities of the kcollect nearest
+            // ---- pass 2: identities of the kcollect nearest.  The second walk only appends
+            // the slots of the points within the kcollect-th distance to a per-lane LDS list (a
+            // short body: nearly every step of the walk has a hit in some lane of the wave).
             float tau = __builtin_inff();
 #pragma unroll
             for (int i = 0; i < K; ++i)
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
-            uint32_t cnt = 0;
+            uint32_t hits = 0;
             walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t s) {
                 const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
                 if (d2 <= tau) {
-                    if (cnt < (uint32_t)CAP) lst[cnt][threadIdx.x] = s;
-                    ++cnt;
+                    if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = s;
+                    ++hits;
                 }
             });
-            if (cnt > (uint32_t)CAP) {  // too many ties at the K-th distance for the list
+            if (hits > (uint32_t)CAP) {  // too many ties at the K-th distance for the list
                 if (a.fail_list) {
                     const uint32_t f = atomicAdd(a.fail_count, 1u);
                     a.fail_list[f] = qi;
                 }
                 continue;
             }
-            TopK<K, true> top;
-            top.init(true);
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const uint32_t slot = lst[j][threadIdx.x];
-                const float4 p = a.spts[slot];
-                top.offer(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w), slot);
+            // A hit's place in the neighbour order is the number of pass-1 distances below its
+            // own: ord[place] = position in the list, no sorting network and no key registers.
+            // Hits at equal distance get the same place; a bitmap of taken places moves the later
+            // one up (the places of a tie group are consecutive and used by nobody else), and an
+            // insertion pass over ord[] then puts tie groups into index order.
+            uint64_t used = 0;
+            bool ties = false;
+            auto place_hit = [&](uint32_t j, const float4 &p) {
+                const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+                uint32_t rank = 0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) rank += (D[i] < d2) ? 1u : 0u;
+                const uint32_t place = rank + (uint32_t)__builtin_ctzll(~(used >> rank));
+                ties |= place != rank;
+                used |= 1ull << place;
+                ord[place][threadIdx.x] = (uint8_t)j;
+            };
+            {
+                uint32_t j = 0;
+                for (; j + 3 < hits; j += 4) {
+                    const float4 p0 = a.spts[lst[j][threadIdx.x]];
+                    const float4 p1 = a.spts[lst[j + 1][threadIdx.x]];
+                    const float4 p2 = a.spts[lst[j + 2][threadIdx.x]];
+                    const float4 p3 = a.spts[lst[j + 3][threadIdx.x]];
+                    place_hit(j, p0);
+                    place_hit(j + 1, p1);
+                    place_hit(j + 2, p2);
+                    place_hit(j + 3, p3);
+                }
+                for (; j < hits; ++j) place_hit(j, a.spts[lst[j][threadIdx.x]]);
+            }
+            if (ties) {
+                auto key_at = [&](uint32_t o) {
+                    const float4 p = a.spts[lst[o][threadIdx.x]];
+                    return make_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+                };
+                for (uint32_t j = 1; j < hits; ++j) {
+                    const uint32_t oj = ord[j][threadIdx.x];
+                    const uint64_t kj = key_at(oj);
+                    uint32_t i = j;
+                    while (i > 0) {
+                        const uint32_t oi = ord[i - 1][threadIdx.x];
+                        if (key_at(oi) <= kj) break;
+                        ord[i][threadIdx.x] = (uint8_t)oi;
+                        --i;
+                    }
+                    ord[i][threadIdx.x] = (uint8_t)oj;
+                }
             }
             KnnOut o2 = out;
             o2.mean = nullptr;  // already written from D[]
-            uint32_t have = top.count();
-            if (have > a.kcollect) have = a.kcollect;
-            consume(SlotNbrs<K>(top.key, top.pay, a.spts), have, true, (size_t)qi, qx, qy, qz, o2);
+            const uint32_t have = hits < a.kcollect ? hits : a.kcollect;
+            consume<true>(LdsNbrs<CAP, GB_THREADS>(lst, ord, a.spts, qx, qy, qz), have, true,
+                          (size_t)qi, qx, qy, qz, o2);
         }
     }
 }
@@ -654,6 +711,24 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
     }
 }
 
+// Second half of the normal estimation: one thread per query turns the covariance sums left by
+// the search kernels into the oriented unit normal.
+__global__ __launch_bounds__(GB_THREADS) void normals_from_cov_kernel(
+    uint32_t nq, const float *cov, size_t stride, const float *qx, const float *qy,
+    const float *qz, KnnOut out) {
+    const uint32_t qi = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (qi >= nq) return;
+    float nnx = 0.0f, nny = 0.0f, nnz = 1.0f;
+    const float c00 = cov[qi];
+    if (c00 >= 0.0f || c00 != c00)
+        normal_from_cov(c00, cov[stride + qi], cov[2 * stride + qi], cov[3 * stride + qi],
+                        cov[4 * stride + qi], cov[5 * stride + qi], qx[qi], qy[qi], qz[qi], out.vp,
+                        nnx, nny, nnz);
+    out.nx[qi] = nnx;
+    out.ny[qi] = nny;
+    out.nz[qi] = nnz;
+}
+
 }  // namespace pcrs
 
 using namespace pcrs;
@@ -836,8 +911,9 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
 
 // ----------------------------------------------------------------------------- host: query
 
-int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed) {
+int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in, uint32_t kneed) {
     pcrs_ctx *ctx = ix->ctx;
+    KnnOut out = out_in;
     if (q.nq == 0) return PCRS_OK;
     if (q.nq >= 0xFFFFFFFFull)
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
@@ -929,7 +1005,14 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
         a.qmode = 1;
         a.nq = nq;
     }
-    pcrs_timing_begin(ctx);  // one bracket around all four stages of the search
+    // normals: the search kernels leave covariance sums, a light kernel solves them afterwards
+    DevBuf cov;
+    if (out.nx && !out.cov) {
+        PCRS_HIP_CHECK(ctx, cov.alloc(ctx, 6 * (size_t)nq * sizeof(float)));
+        out.cov = cov.as<float>();
+        out.cov_stride = nq;
+    }
+    pcrs_timing_begin(ctx);  // one bracket around all stages of the search
     launch(blocks1);
 
     // stages 2-4: larger cubes over the failures, one wave per query (their number is known only
@@ -964,6 +1047,14 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, u
     // stage 4: brute force over what is left
     const int rc_bf = pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, src,
                                          &counters[3], nq);
+    if (cov.p && rc_bf == PCRS_OK) {
+        const float *cqx = q.self ? ix->x + q.out_offset : q.qx;
+        const float *cqy = q.self ? ix->y + q.out_offset : q.qy;
+        const float *cqz = q.self ? ix->z + q.out_offset : q.qz;
+        hipLaunchKernelGGL(normals_from_cov_kernel, dim3((nq + GB_THREADS - 1) / GB_THREADS),
+                           dim3(GB_THREADS), 0, ctx->stream, nq, cov.as<float>(), (size_t)nq, cqx,
+                           cqy, cqz, out);
+    }
     pcrs_timing_end(ctx);
     PCRS_TRY(rc_bf);
     // self queries answered from the sorted array never saw the non-finite points of the range

@@ -131,6 +131,50 @@ struct SlotNbrs {  // keys + sorted-slot payloads in registers, coordinates from
     }
 };
 
+// This lane's neighbours in LDS (column threadIdx.x): lst[] holds their sorted slots in no
+// particular order, ord[r] the position in lst[] of the r-th neighbour.  Keys are recomputed
+// from the point (one float4 load per neighbour, four in flight).
+template <int ROWS, int COLS>
+struct LdsNbrs {
+    const uint32_t (&lst)[ROWS][COLS];
+    const uint8_t (&ord)[ROWS][COLS];
+    const float4 *spts;
+    float qx, qy, qz;
+    __device__ __forceinline__ LdsNbrs(const uint32_t (&l)[ROWS][COLS],
+                                       const uint8_t (&o)[ROWS][COLS], const float4 *s, float x,
+                                       float y, float z)
+        : lst(l), ord(o), spts(s), qx(x), qy(y), qz(z) {}
+    __device__ __forceinline__ uint64_t key_of(const float4 &p) const {
+        return make_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+    }
+    __device__ __forceinline__ uint32_t slot(uint32_t r) const {
+        return lst[ord[r][threadIdx.x]][threadIdx.x];
+    }
+    template <class F>
+    __device__ __forceinline__ void for_each(uint32_t c, F f) const {
+        uint32_t j = 0;
+        for (; j + 3 < c; j += 4) {
+            const uint32_t s0 = slot(j), s1 = slot(j + 1), s2 = slot(j + 2), s3 = slot(j + 3);
+            const float4 p0 = spts[s0], p1 = spts[s1], p2 = spts[s2], p3 = spts[s3];
+            f(j, key_of(p0), s0);
+            f(j + 1, key_of(p1), s1);
+            f(j + 2, key_of(p2), s2);
+            f(j + 3, key_of(p3), s3);
+        }
+        for (; j < c; ++j) {
+            const uint32_t s0 = slot(j);
+            f(j, key_of(spts[s0]), s0);
+        }
+    }
+    __device__ __forceinline__ void fetch(uint64_t, uint32_t slot, float &x, float &y,
+                                          float &z) const {
+        const float4 p = spts[slot];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+    }
+};
+
 struct ListNbrs {  // ascending keys of this query in memory
     const uint64_t *key;
     const float *rx, *ry, *rz;
@@ -203,9 +247,31 @@ __device__ inline void smallest_eigvec_3x3(float f00, float f01, float f02, floa
     oz = (float)(ez * inv);
 }
 
+// estimate.rs:83-109 — eigenvector of the covariance, normalised, flipped towards the viewpoint.
+__device__ __forceinline__ void normal_from_cov(float c00, float c01, float c02, float c11,
+                                                float c12, float c22, float qx, float qy, float qz,
+                                                const float *vp, float &nnx, float &nny,
+                                                float &nnz) {
+    smallest_eigvec_3x3(c00, c01, c02, c11, c12, c22, nnx, nny, nnz);
+    const float len = sqrtf((nnx * nnx + nny * nny) + nnz * nnz);
+    if (len > 1e-10f) {
+        nnx /= len;
+        nny /= len;
+        nnz /= len;
+    }
+    const float vx = vp[0] - qx, vy = vp[1] - qy, vz = vp[2] - qz;
+    const float dot = (nnx * vx + nny * vy) + nnz * vz;
+    if (dot < 0.0f) {
+        nnx = -nnx;
+        nny = -nny;
+        nnz = -nnz;
+    }
+}
+
 // Per-query consumers.  `cnt` = valid neighbours available (ascending), `qvalid` = finite query,
 // `qo` = output slot; neighbour coordinates come from the accessor's fetch().
-template <class Nbrs>
+// COV_ONLY promises that o.cov is set whenever o.nx is, and leaves the solver out of the kernel.
+template <bool COV_ONLY = false, class Nbrs>
 __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvalid, size_t qo,
                                         float qx, float qy, float qz, const KnnOut &o) {
     if (!qvalid) cnt = 0;
@@ -281,20 +347,20 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
                 c12 += dy * dz;
                 c22 += dz * dz;
             });
-            smallest_eigvec_3x3(c00, c01, c02, c11, c12, c22, nnx, nny, nnz);
-            const float len = sqrtf((nnx * nnx + nny * nny) + nnz * nnz);
-            if (len > 1e-10f) {
-                nnx /= len;
-                nny /= len;
-                nnz /= len;
+            if (COV_ONLY || o.cov) {  // the eigenvector is solved by normals_from_cov_kernel
+                o.cov[qo] = c00;
+                o.cov[o.cov_stride + qo] = c01;
+                o.cov[2 * o.cov_stride + qo] = c02;
+                o.cov[3 * o.cov_stride + qo] = c11;
+                o.cov[4 * o.cov_stride + qo] = c12;
+                o.cov[5 * o.cov_stride + qo] = c22;
+                return;
             }
-            const float vx = o.vp[0] - qx, vy = o.vp[1] - qy, vz = o.vp[2] - qz;
-            const float dot = (nnx * vx + nny * vy) + nnz * vz;
-            if (dot < 0.0f) {
-                nnx = -nnx;
-                nny = -nny;
-                nnz = -nnz;
-            }
+            if constexpr (!COV_ONLY)
+                normal_from_cov(c00, c01, c02, c11, c12, c22, qx, qy, qz, o.vp, nnx, nny, nnz);
+        } else if (COV_ONLY || o.cov) {
+            o.cov[qo] = -1.0f;  // no neighbours (a variance is never negative)
+            return;
         }
         o.nx[qo] = nnx;
         o.ny[qo] = nny;

@@ -10,7 +10,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libpcrs_hip.so"))
+# PCRS_HIP_LIB names another build of the same library (used to compare kernel variants)
+LIB_PATH = os.environ.get("PCRS_HIP_LIB") or os.path.normpath(
+    os.path.join(_HERE, "..", "lib", "libpcrs_hip.so"))
 
 PCRS_OK = 0
 PCRS_ERR_INVALID_ARG = -1

@@ -726,6 +726,9 @@ struct pcrs_icp {
     DevBuf own_s[3], own_t[3], own_n[3];
     DevBuf cur[3];
     DevBuf nn_idx, nn_d2, sums;
+    // source in the cell order of a grid over itself (neighbouring lanes then search neighbouring
+    // target cells); perm[i] = original index of sorted point i, empty = original order kept
+    DevBuf ord_s[3], perm;
 };
 
 namespace {
@@ -746,6 +749,37 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
     PCRS_TRY(run_query(target, q, o, 1));
     return pcrs_launch_icp_reduce(ctx, mode, cx, cy, cz, n, target->x, target->y, target->z, tnx,
                                   tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums);
+}
+
+// Reorders the source spatially.  The sums of an ICP step do not depend on the order of the
+// correspondences beyond f64 rounding, and pcrs_icp_get_current undoes the permutation.
+int icp_order_source(pcrs_icp *icp) {
+    pcrs_ctx *ctx = icp->ctx;
+    const size_t n = icp->n;
+    if (n < 4096) return PCRS_OK;
+    pcrs_index *tmp = nullptr;
+    PCRS_TRY(pcrs_index_build_dev(ctx, icp->sx, icp->sy, icp->sz, n, 8, PCRS_ALGO_AUTO, &tmp));
+    int rc = PCRS_OK;
+    if (tmp->algo == PCRS_ALGO_GRID && tmp->nvalid == n) {  // all finite
+        for (int a = 0; a < 3 && rc == PCRS_OK; ++a)
+            if (icp->ord_s[a].alloc(n * sizeof(float)) != hipSuccess)
+                rc = pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed");
+        if (rc == PCRS_OK && icp->perm.alloc(n * sizeof(uint32_t)) != hipSuccess)
+            rc = pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed");
+        if (rc == PCRS_OK)
+            rc = pcrs_grid_sorted_columns(tmp, icp->ord_s[0].as<float>(), icp->ord_s[1].as<float>(),
+                                          icp->ord_s[2].as<float>(), icp->perm.as<uint32_t>());
+        if (rc == PCRS_OK) {
+            icp->sx = icp->ord_s[0].as<float>();
+            icp->sy = icp->ord_s[1].as<float>();
+            icp->sz = icp->ord_s[2].as<float>();
+        } else {
+            icp->perm.release();
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);  // tmp's buffers are still in use by the kernels above
+    pcrs_index_destroy(tmp);
+    return rc;
 }
 
 int icp_alloc_work(pcrs_icp *icp) {
@@ -832,6 +866,7 @@ int pcrs_icp_create_dev(pcrs_ctx *ctx, const float *dsx, const float *dsy, const
     icp->tnz = have_n ? dtnz : nullptr;
     icp->n_normals = have_n ? n_normals : 0;
     int rc = pcrs_index_build_dev(ctx, dtx, dty, dtz, m, 1, PCRS_ALGO_AUTO, &icp->target);
+    if (rc == PCRS_OK) rc = icp_order_source(icp);
     if (rc == PCRS_OK) rc = icp_alloc_work(icp);
     if (rc == PCRS_OK) rc = pcrs_icp_reset(icp);
     if (rc != PCRS_OK) {
@@ -875,6 +910,7 @@ int pcrs_icp_create(pcrs_ctx *ctx, const float *sx, const float *sy, const float
         rc = pcrs_index_build_dev(ctx, icp->own_t[0].as<float>(), icp->own_t[1].as<float>(),
                                   icp->own_t[2].as<float>(), m, 1, PCRS_ALGO_AUTO, &icp->target);
     }
+    if (rc == PCRS_OK) rc = icp_order_source(icp);
     if (rc == PCRS_OK) rc = icp_alloc_work(icp);
     if (rc == PCRS_OK) rc = pcrs_icp_reset(icp);
     if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -956,8 +992,18 @@ int pcrs_icp_get_current(pcrs_icp *icp, float *x, float *y, float *z) {
     pcrs_ctx *ctx = icp->ctx;
     PCRS_TRY(bind_device(ctx));
     float *o[3] = {x, y, z};
-    for (int a = 0; a < 3; ++a)
-        if (o[a]) PCRS_TRY(download(ctx, o[a], icp->cur[a].p, icp->n * sizeof(float)));
+    DevBuf tmp;
+    if (icp->perm.p) PCRS_HIP_CHECK(ctx, tmp.alloc(ctx, icp->n * sizeof(float)));
+    for (int a = 0; a < 3; ++a) {
+        if (!o[a]) continue;
+        const void *src = icp->cur[a].p;
+        if (icp->perm.p) {  // back to the caller's point order
+            PCRS_TRY(pcrs_launch_scatter_perm(ctx, icp->cur[a].as<float>(),
+                                              icp->perm.as<uint32_t>(), icp->n, tmp.as<float>()));
+            src = tmp.p;
+        }
+        PCRS_TRY(download(ctx, o[a], src, icp->n * sizeof(float)));
+    }
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
 }

@@ -456,6 +456,63 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
     }
 }
 
+// Wave-cooperative walk over the rows of a box of cells: f(p, valid, slot) is called by the whole
+// wave for every 64-point piece of every row.  The lanes first fetch the row ranges in parallel
+// (one memory latency for up to 64 rows), then the points of four rows are requested before any
+// is used: a retried query is a single wave, so nothing else hides its load latency.
+template <class F>
+__device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int y0, int y1, int z0,
+                                          int z1, int lane, F f) {
+    const GridGeom &g = a.g;
+    const int ny = y1 - y0 + 1;
+    const int nrows = ny * (z1 - z0 + 1);
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int rbase = 0; rbase < nrows; rbase += 64) {
+        const int r = rbase + lane;
+        uint32_t ms0 = 0, ms1 = 0;
+        if (r < nrows) {
+            const int zz = z0 + r / ny, yy = y0 + r % ny;
+            const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+            ms0 = a.cell_start[row + x0];
+            ms1 = a.cell_start[row + x1 + 1];
+        }
+        const int cnt = min(64, nrows - rbase);
+        auto tail = [&](uint32_t s0, uint32_t s1) {
+            for (uint32_t sb = s0 + 64; sb < s1; sb += 64) {
+                const uint32_t s = sb + lane;
+                const bool v = s < s1;
+                f(v ? a.spts[s] : zero, v, s);
+            }
+        };
+        int i = 0;
+        for (; i + 3 < cnt; i += 4) {
+            const uint32_t b0 = __builtin_amdgcn_readlane(ms0, i), e0 = __builtin_amdgcn_readlane(ms1, i);
+            const uint32_t b1 = __builtin_amdgcn_readlane(ms0, i + 1), e1 = __builtin_amdgcn_readlane(ms1, i + 1);
+            const uint32_t b2 = __builtin_amdgcn_readlane(ms0, i + 2), e2 = __builtin_amdgcn_readlane(ms1, i + 2);
+            const uint32_t b3 = __builtin_amdgcn_readlane(ms0, i + 3), e3 = __builtin_amdgcn_readlane(ms1, i + 3);
+            const bool v0 = b0 + lane < e0, v1 = b1 + lane < e1, v2 = b2 + lane < e2, v3 = b3 + lane < e3;
+            const float4 p0 = v0 ? a.spts[b0 + lane] : zero;
+            const float4 p1 = v1 ? a.spts[b1 + lane] : zero;
+            const float4 p2 = v2 ? a.spts[b2 + lane] : zero;
+            const float4 p3 = v3 ? a.spts[b3 + lane] : zero;
+            f(p0, v0, b0 + lane);
+            tail(b0, e0);
+            f(p1, v1, b1 + lane);
+            tail(b1, e1);
+            f(p2, v2, b2 + lane);
+            tail(b2, e2);
+            f(p3, v3, b3 + lane);
+            tail(b3, e3);
+        }
+        for (; i < cnt; ++i) {
+            const uint32_t b0 = __builtin_amdgcn_readlane(ms0, i), e0 = __builtin_amdgcn_readlane(ms1, i);
+            const bool v0 = b0 + lane < e0;
+            f(v0 ? a.spts[b0 + lane] : zero, v0, b0 + lane);
+            tail(b0, e0);
+        }
+    }
+}
+
 // Retry kernel: ONE WAVE PER QUERY.  The queries that the per-lane kernel could not certify are
 // few and scattered, so a lane-per-query retry would be a handful of long serial walks.  Here the
 // 64 lanes of a wave share one query: they stride over each row of the (2R+1)^3 cube (coalesced
@@ -493,20 +550,14 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
 #pragma unroll
             for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
-            for (int zz = z0; zz <= z1; ++zz)
-                for (int yy = y0; yy <= y1; ++yy) {
-                    const uint32_t row =
-                        ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
-                    const uint32_t s0 = a.cell_start[row + x0], s1 = a.cell_start[row + x1 + 1];
-                    for (uint32_t s = s0 + lane; s < s1; s += 64) {
-                        const float4 p = a.spts[s];
-                        const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+            wave_walk(a, x0, x1, y0, y1, z0, z1, lane, [&](const float4 &p, bool valid, uint32_t) {
+                if (valid) {
+                    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
 #pragma unroll
-                        for (int t = K - 1; t > 0; --t)
-                            D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
-                        D[0] = fminf(D[0], d2);
-                    }
+                    for (int t = K - 1; t > 0; --t) D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
+                    D[0] = fminf(D[0], d2);
                 }
+            });
             // butterfly merge of the 64 per-lane lists
 #pragma unroll 1
             for (int r = 1; r < 64; r <<= 1) {
@@ -555,26 +606,15 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             for (int i = 0; i < K; ++i)
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
             uint32_t base = 0;
-            for (int zz = z0; zz <= z1; ++zz)
-                for (int yy = y0; yy <= y1; ++yy) {
-                    const uint32_t row =
-                        ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
-                    const uint32_t s0 = a.cell_start[row + x0], s1 = a.cell_start[row + x1 + 1];
-                    for (uint32_t sb = s0; sb < s1; sb += 64) {
-                        const uint32_t s = sb + lane;
-                        bool hit = false;
-                        if (s < s1) {
-                            const float4 p = a.spts[s];
-                            hit = sqdist(qx, qy, qz, p.x, p.y, p.z) <= tau;
-                        }
-                        const unsigned long long mask = __ballot(hit);
-                        if (hit) {
-                            const uint32_t at = base + (uint32_t)__popcll(mask & lt_mask);
-                            if (at < 64u) wl_slot[w][at] = s;
-                        }
-                        base += (uint32_t)__popcll(mask);
-                    }
+            wave_walk(a, x0, x1, y0, y1, z0, z1, lane, [&](const float4 &p, bool valid, uint32_t s) {
+                const bool hit = valid && sqdist(qx, qy, qz, p.x, p.y, p.z) <= tau;
+                const unsigned long long mask = __ballot(hit);
+                if (hit) {
+                    const uint32_t at = base + (uint32_t)__popcll(mask & lt_mask);
+                    if (at < 64u) wl_slot[w][at] = s;
                 }
+                base += (uint32_t)__popcll(mask);
+            });
             if (base > 64u) {
                 failed = true;  // more ties at the K-th distance than the list holds
             } else {
@@ -709,6 +749,40 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
         out.nn_idx[qi] = (best == PCRS_EMPTY_KEY) ? PCRS_NO_INDEX : key_idx(best);
         if (out.nn_d2) out.nn_d2[qi] = best_d2;
     }
+}
+
+// Puts the points of every cell into ascending original-index order (one thread per cell; the
+// scatter's atomics leave them in arrival order).  Used where a reproducible point order matters.
+__global__ __launch_bounds__(GB_THREADS) void sort_cells_kernel(const uint32_t *cell_start,
+                                                                uint32_t ncell, float4 *spts) {
+    const uint32_t c = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (c >= ncell) return;
+    const uint32_t s0 = cell_start[c], s1 = cell_start[c + 1];
+    for (uint32_t j = s0 + 1; j < s1; ++j) {
+        const float4 pj = spts[j];
+        const uint32_t kj = __float_as_uint(pj.w);
+        uint32_t i = j;
+        while (i > s0) {
+            const float4 pi = spts[i - 1];
+            if (__float_as_uint(pi.w) <= kj) break;
+            spts[i] = pi;
+            --i;
+        }
+        spts[i] = pj;
+    }
+}
+
+// Columns of the cell-sorted points plus the permutation (sorted position -> original index).
+__global__ __launch_bounds__(GB_THREADS) void unpack_sorted_kernel(const float4 *spts, uint32_t n,
+                                                                   float *ox, float *oy, float *oz,
+                                                                   uint32_t *perm) {
+    const uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = spts[i];
+    ox[i] = p.x;
+    oy[i] = p.y;
+    oz[i] = p.z;
+    perm[i] = __float_as_uint(p.w);
 }
 
 // Second half of the normal estimation: one thread per query turns the covariance sums left by
@@ -906,6 +980,20 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
     ix->g = g;
     ix->ncell = ncell;
     ix->algo = PCRS_ALGO_GRID;
+    return PCRS_OK;
+}
+
+int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (ix->algo != PCRS_ALGO_GRID || ix->nvalid == 0)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "index has no grid");
+    hipLaunchKernelGGL(sort_cells_kernel, dim3((ix->ncell + GB_THREADS - 1) / GB_THREADS),
+                       dim3(GB_THREADS), 0, ctx->stream, ix->cell_start.as<uint32_t>(), ix->ncell,
+                       ix->spts.as<float4>());
+    const uint32_t n = (uint32_t)ix->nvalid;
+    hipLaunchKernelGGL(unpack_sorted_kernel, dim3((n + GB_THREADS - 1) / GB_THREADS),
+                       dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(), n, ox, oy, oz, perm);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
 

@@ -12,8 +12,24 @@ __global__ __launch_bounds__(256) void mask_kernel(const float *__restrict__ mea
                                                    float thr, uint8_t *__restrict__ keep,
                                                    unsigned long long *count) {
     unsigned local = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
+    // four means per thread: one 16-byte load, one 4-byte store (hipMalloc'd columns are aligned)
+    const size_t n4 = n / 4;
+    const float4 *mean4 = reinterpret_cast<const float4 *>(mean);
+    uint32_t *keep4 = reinterpret_cast<uint32_t *>(keep);
+    const bool vec = ((reinterpret_cast<uintptr_t>(mean) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(keep) & 3u) == 0);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t done = 0;
+    if (vec) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float4 m = mean4[i];
+            const uint32_t k0 = m.x <= thr, k1 = m.y <= thr, k2 = m.z <= thr, k3 = m.w <= thr;
+            keep4[i] = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
+            local += k0 + k1 + k2 + k3;
+        }
+        done = n4 * 4;
+    }
+    for (size_t i = done + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const bool k = mean[i] <= thr;
         keep[i] = k ? 1 : 0;
         local += k ? 1u : 0u;
@@ -207,8 +223,27 @@ int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint
                      unsigned long long *d_count) {
     if (d_count) PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(*d_count), ctx->stream));
     if (n == 0) return PCRS_OK;
-    hipLaunchKernelGGL(mask_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, ctx->stream,
-                       mean, n, thr, keep, d_count);
+    // one block per CU at most: every block ends with an atomic on the same counter
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > (size_t)ctx->num_cus) blocks = (size_t)ctx->num_cus;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(mask_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mean, n, thr,
+                       keep, d_count);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+__global__ __launch_bounds__(256) void scatter_perm_kernel(const float *in, const uint32_t *perm,
+                                                           size_t n, float *out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[perm[i]] = in[i];
+}
+
+int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *perm, size_t n,
+                             float *out) {
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, in, perm, n, out);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

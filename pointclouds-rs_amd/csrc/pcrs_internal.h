@@ -179,6 +179,9 @@ int pcrs_launch_knn_bf(pcrs_ctx *ctx, const float *rx, const float *ry, const fl
 
 // ---- grid (grid.hip)
 int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint);
+// Writes the points in cell order (ties inside a cell by original index) as columns, with the
+// permutation sorted position -> original index.  Needs algo == GRID; all nvalid points.
+int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm);
 int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed);
 // consumer defaults for the non-finite queries of a self-query range (knn_bf.hip)
 int pcrs_launch_invalid_defaults(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
@@ -187,6 +190,9 @@ int pcrs_launch_invalid_defaults(pcrs_ctx *ctx, const float *rx, const float *ry
 // ---- misc kernels (misc.hip)
 int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint8_t *keep,
                      unsigned long long *d_count);
+// out[perm[i]] = in[i]
+int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *perm, size_t n,
+                             float *out);
 int pcrs_launch_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                           const float rot[9], const float t[3], float *ox, float *oy, float *oz);
 int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,

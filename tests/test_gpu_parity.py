@@ -205,6 +205,27 @@ def test_correspondences_and_step_sums(hip, oracle, algo):
     icp.close()
 
 
+@pytest.mark.parametrize("n", [1000, 20000], ids=["unordered", "cell-ordered"])
+def test_icp_current_keeps_caller_order(hip, oracle, n):
+    """Large sources are reordered spatially inside the ICP object; the caller never sees it."""
+    from pointclouds_rs import _ffi
+
+    tgt = gen.hemisphere(n, 7, 5.0)
+    src = oracle.apply_transform(*tgt, gen.rot_z(0.03), (0.1, -0.05, 0.02))
+    rot, t = gen.rot_z(-0.01), (0.01, 0.02, -0.03)
+    icp = hip.Icp(src, tgt, None)
+    s0 = icp.accumulate(_ffi.ICP_POINT_TO_POINT, np.inf)
+    icp.apply(rot, t)
+    cur = icp.current()
+    ref = oracle.apply_transform(*oracle.apply_transform(*src, np.eye(3, dtype=np.float32), (0, 0, 0)),
+                                 rot, t)
+    for a in range(3):
+        assert np.array_equal(cur[a].view(np.uint32), ref[a].view(np.uint32))
+    r = oracle.icp_step(src, tgt, None, np.inf, algo=1)
+    assert s0[0] == r["n_corr"] and np.isclose(s0[1], r["sum_d2"], rtol=1e-12)
+    icp.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1], ids=["point", "plane"])
 def test_icp_run_matches_oracle(hip, oracle, mode):
     tgt = _icp_pair(4000)

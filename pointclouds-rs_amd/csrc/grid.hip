@@ -203,6 +203,119 @@ __global__ __launch_bounds__(GB_THREADS) void scatter_kernel(const float *x, con
     }
 }
 
+// ---- two-level counting sort by cell (no global atomics)
+// Level 1 splits the cloud into <= 8192 coarse buckets of 2^shift consecutive cells with per-block
+// LDS histograms (bucket-major table of per-block counts -> exclusive scan -> per-block write
+// cursors).  Level 2 gives every bucket to one block, which histograms its 2^shift cells in LDS,
+// scans them into cell_start[] and places the points.  Both levels use LDS atomics only; the
+// global-memory version above needs one device-scope atomic per point and pass.
+struct SortPlan {
+    GridGeom g;
+    uint32_t shift;    // log2(cells per coarse bucket), <= FINE_MAX_SHIFT
+    uint32_t nb;       // coarse buckets
+    uint32_t nblk;     // level-1 blocks
+    uint32_t per_blk;  // points per level-1 block
+    uint32_t ncell;
+};
+constexpr uint32_t FINE_MAX_SHIFT = 12;
+
+__global__ __launch_bounds__(GB_THREADS) void coarse_hist_kernel(const float *x, const float *y,
+                                                                 const float *z, uint32_t m,
+                                                                 SortPlan sp, uint32_t *table) {
+    extern __shared__ uint32_t hist[];
+    for (uint32_t t = threadIdx.x; t < sp.nb; t += GB_THREADS) hist[t] = 0;
+    __syncthreads();
+    const uint32_t begin = blockIdx.x * sp.per_blk;
+    const uint32_t end = min(m, begin + sp.per_blk);
+    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
+        const float px = x[i], py = y[i], pz = z[i];
+        if (finite3(px, py, pz)) atomicAdd(&hist[cell_index(sp.g, px, py, pz) >> sp.shift], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < sp.nb; t += GB_THREADS)
+        table[(size_t)t * sp.nblk + blockIdx.x] = hist[t];
+}
+
+__global__ __launch_bounds__(GB_THREADS) void coarse_scatter_kernel(const float *x, const float *y,
+                                                                    const float *z, uint32_t m,
+                                                                    SortPlan sp,
+                                                                    const uint32_t *table,
+                                                                    float4 *tmp) {
+    extern __shared__ uint32_t cursor[];
+    for (uint32_t t = threadIdx.x; t < sp.nb; t += GB_THREADS)
+        cursor[t] = table[(size_t)t * sp.nblk + blockIdx.x];
+    __syncthreads();
+    const uint32_t begin = blockIdx.x * sp.per_blk;
+    const uint32_t end = min(m, begin + sp.per_blk);
+    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
+        const float px = x[i], py = y[i], pz = z[i];
+        if (finite3(px, py, pz)) {
+            const uint32_t at = atomicAdd(&cursor[cell_index(sp.g, px, py, pz) >> sp.shift], 1u);
+            tmp[at] = make_float4(px, py, pz, __uint_as_float(i));
+        }
+    }
+}
+
+__global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp, SortPlan sp,
+                                                               const uint32_t *table,
+                                                               uint32_t *cell_start, float4 *spts,
+                                                               uint32_t *nonempty) {
+    __shared__ uint32_t cnt[1u << FINE_MAX_SHIFT];
+    __shared__ uint32_t wsum[GB_THREADS / 64];
+    const uint32_t b = blockIdx.x;
+    const uint32_t cpb = 1u << sp.shift;
+    const uint32_t cell0 = b << sp.shift;
+    const uint32_t ncl = min(cpb, sp.ncell - cell0);
+    const uint32_t begin = table[(size_t)b * sp.nblk];
+    const uint32_t end = table[(size_t)(b + 1) * sp.nblk];  // the scan's total closes the table
+    for (uint32_t t = threadIdx.x; t < cpb; t += GB_THREADS) cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
+        const float4 p = tmp[i];
+        atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..cpb): each thread owns cpb/256 consecutive cells
+    const uint32_t ipt = (cpb + GB_THREADS - 1) / GB_THREADS;
+    const uint32_t f0 = threadIdx.x * ipt;
+    uint32_t local = 0, opened = 0;
+    for (uint32_t j = 0; j < ipt; ++j) {
+        const uint32_t f = f0 + j;
+        if (f < cpb) {
+            local += cnt[f];
+            opened += cnt[f] ? 1u : 0u;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    for (int off = 32; off > 0; off >>= 1) opened += __shfl_down(opened, off, 64);
+    if (lane == 0 && opened) atomicAdd(nonempty, opened);
+    __syncthreads();
+    uint32_t run = begin + incl - local;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (uint32_t j = 0; j < ipt; ++j) {
+        const uint32_t f = f0 + j;
+        if (f < cpb) {
+            const uint32_t c = cnt[f];
+            cnt[f] = run;  // becomes the write cursor of the cell
+            if (f < ncl) cell_start[cell0 + f] = run;
+            run += c;
+        }
+    }
+    if (b == sp.nb - 1 && threadIdx.x == 0) cell_start[sp.ncell] = end;
+    __syncthreads();
+    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
+        const float4 p = tmp[i];
+        const uint32_t at = atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u);
+        spts[at] = p;
+    }
+}
+
 // ----------------------------------------------------------------------------- query kernel
 
 struct CellArgs {
@@ -866,6 +979,30 @@ void make_geometry(const double lo[3], const double ext[3], double emax, double 
     *cell_used = cell;
 }
 
+// Shape of the two-level sort for this grid; false when the grid has more cells than 8192 coarse
+// buckets of 4096 (the global-atomic counting sort handles those).
+bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
+    // experiments only: PCRS_GRID_SORT=atomic keeps the one-level sort
+    if (const char *e = getenv("PCRS_GRID_SORT"))
+        if (e[0] == 'a') return false;
+    const uint32_t nb_max = ncell <= (1024u << FINE_MAX_SHIFT) ? 1024u : 8192u;
+    uint32_t shift = 0;
+    while (((ncell + (1u << shift) - 1) >> shift) > nb_max) ++shift;
+    if (shift > FINE_MAX_SHIFT) return false;
+    sp->g = g;
+    sp->shift = shift;
+    sp->nb = (ncell + (1u << shift) - 1) >> shift;
+    sp->ncell = ncell;
+    uint32_t nblk = (m + 4095) / 4096;
+    if (nblk > 2048) nblk = 2048;
+    if (nblk == 0) nblk = 1;
+    uint32_t per = (m + nblk - 1) / nblk;
+    per = (per + GB_THREADS - 1) / GB_THREADS * GB_THREADS;
+    sp->nblk = (m + per - 1) / per;
+    sp->per_blk = per;
+    return true;
+}
+
 }  // namespace
 
 int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
@@ -915,21 +1052,54 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
     const double max_cells = 4.0 * (double)nvalid + 4096.0;
     GridGeom g{};
     uint32_t ncell = 0;
-    DevBuf counts, cell_id;
-    PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
+    DevBuf counts, cell_id, table, table_sums, tmp, sorted;
     // sized for the largest grid the budget allows: no reallocation between attempts
     PCRS_HIP_CHECK(ctx, counts.alloc(ctx, ((size_t)max_cells + 8) * sizeof(uint32_t)));
     uint32_t *h_nonempty = reinterpret_cast<uint32_t *>(pin);
+    bool sorted_done = false;  // the accepted attempt already left cell_start[] and the points
     for (int attempt = 0;; ++attempt) {
         double used = cell;
         make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
         cell = used;
-        PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
-                                           ctx->stream));
         uint32_t *d_nonempty = counts.as<uint32_t>() + ncell + 1;
-        hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
-                           ix->y, ix->z, m, g, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
-                           d_nonempty);
+        SortPlan sp{};
+        const bool two_level = plan_sort(g, ncell, m, &sp);
+        if (two_level) {
+            // the whole sort is cheaper than one pass of global atomics, so every attempt sorts
+            const size_t entries = (size_t)sp.nb * sp.nblk;
+            if (!table.p) {
+                PCRS_HIP_CHECK(ctx, table.alloc(ctx, ((size_t)8192 * sp.nblk + 8) * sizeof(uint32_t)));
+                PCRS_HIP_CHECK(ctx, table_sums.alloc(
+                                        ctx, (((size_t)8192 * sp.nblk) / SCAN_BLOCK + 2) * sizeof(uint32_t)));
+                PCRS_HIP_CHECK(ctx, tmp.alloc(ctx, nvalid * sizeof(float4)));
+                PCRS_HIP_CHECK(ctx, sorted.alloc(ctx, nvalid * sizeof(float4)));
+            }
+            PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_nonempty, 0, sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(coarse_hist_kernel, dim3(sp.nblk), dim3(GB_THREADS),
+                               sp.nb * sizeof(uint32_t), ctx->stream, ix->x, ix->y, ix->z, m, sp,
+                               table.as<uint32_t>());
+            const uint32_t tblocks = (uint32_t)((entries + SCAN_BLOCK - 1) / SCAN_BLOCK);
+            hipLaunchKernelGGL(scan_block_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream,
+                               table.as<uint32_t>(), (uint32_t)entries, table_sums.as<uint32_t>());
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                               table_sums.as<uint32_t>(), tblocks, table.as<uint32_t>() + entries);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream,
+                               table.as<uint32_t>(), (uint32_t)entries, table_sums.as<uint32_t>());
+            hipLaunchKernelGGL(coarse_scatter_kernel, dim3(sp.nblk), dim3(GB_THREADS),
+                               sp.nb * sizeof(uint32_t), ctx->stream, ix->x, ix->y, ix->z, m, sp,
+                               table.as<uint32_t>(), tmp.as<float4>());
+            hipLaunchKernelGGL(fine_sort_kernel, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream,
+                               tmp.as<float4>(), sp, table.as<uint32_t>(), counts.as<uint32_t>(),
+                               sorted.as<float4>(), d_nonempty);
+        } else {
+            if (!cell_id.p) PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
+            PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
+                                               ctx->stream));
+            hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
+                               ix->y, ix->z, m, g, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
+                               d_nonempty);
+        }
+        sorted_done = two_level;
         if (attempt == 3) break;
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_nonempty, d_nonempty, sizeof(uint32_t),
                                            hipMemcpyDeviceToHost, ctx->stream));
@@ -951,25 +1121,36 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
         cell = next;
     }
 
-    // 3. scan the histogram into slot ranges and scatter the points.  All buffers come from the
-    //    context's pool, so the temporaries are released without waiting for the stream.
-    DevBuf scan_sums, fill;
-    const uint32_t nblocks = (ncell + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    PCRS_HIP_CHECK(ctx, scan_sums.alloc(ctx, ((size_t)nblocks + 1) * sizeof(uint32_t)));
-    hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream,
-                       counts.as<uint32_t>(), ncell, scan_sums.as<uint32_t>());
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       scan_sums.as<uint32_t>(), nblocks, counts.as<uint32_t>() + ncell);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream,
-                       counts.as<uint32_t>(), ncell, scan_sums.as<uint32_t>());
-    PCRS_HIP_CHECK(ctx, fill.alloc(ctx, (size_t)ncell * sizeof(uint32_t)));
-    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(fill.p, counts.p, (size_t)ncell * sizeof(uint32_t),
-                                       hipMemcpyDeviceToDevice, ctx->stream));
-    PCRS_HIP_CHECK(ctx, ix->spts.alloc(ctx, nvalid * sizeof(float4)));
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
-                       ix->z, m, cell_id.as<uint32_t>(), fill.as<uint32_t>(),
-                       ix->spts.as<float4>());
-    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    if (sorted_done) {
+        PCRS_HIP_CHECK(ctx, hipGetLastError());
+        ix->spts.release();
+        ix->spts.p = sorted.p;
+        ix->spts.bytes = sorted.bytes;
+        ix->spts.owner = sorted.owner;
+        sorted.p = nullptr;
+        sorted.bytes = 0;
+        sorted.owner = nullptr;
+    } else {
+        // scan the histogram into slot ranges and scatter the points.  All buffers come from the
+        // context's pool, so the temporaries are released without waiting for the stream.
+        DevBuf scan_sums, fill;
+        const uint32_t nblocks = (ncell + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        PCRS_HIP_CHECK(ctx, scan_sums.alloc(ctx, ((size_t)nblocks + 1) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream,
+                           counts.as<uint32_t>(), ncell, scan_sums.as<uint32_t>());
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                           scan_sums.as<uint32_t>(), nblocks, counts.as<uint32_t>() + ncell);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream,
+                           counts.as<uint32_t>(), ncell, scan_sums.as<uint32_t>());
+        PCRS_HIP_CHECK(ctx, fill.alloc(ctx, (size_t)ncell * sizeof(uint32_t)));
+        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(fill.p, counts.p, (size_t)ncell * sizeof(uint32_t),
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+        PCRS_HIP_CHECK(ctx, ix->spts.alloc(ctx, nvalid * sizeof(float4)));
+        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
+                           ix->z, m, cell_id.as<uint32_t>(), fill.as<uint32_t>(),
+                           ix->spts.as<float4>());
+        PCRS_HIP_CHECK(ctx, hipGetLastError());
+    }
     ix->cell_start.release();
     ix->cell_start.p = counts.p;  // take ownership of the scanned histogram
     ix->cell_start.bytes = counts.bytes;
@@ -1147,7 +1328,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     PCRS_TRY(rc_bf);
     // self queries answered from the sorted array never saw the non-finite points of the range
     if (q.self && !nn_only && ix->nvalid < ix->m)
-        PCRS_TRY(pcrs_launch_invalid_defaults(ctx, ix->x, ix->y, ix->z, q, out));
+        PCRS_TRY(pcrs_launch_invalid_defaults(ctx, ix->x, ix->y, ix->z, q, out_in));  // no cov
     ix->stats_dev = counters;
     ix->stats_nq = nq;
     return PCRS_OK;

@@ -206,25 +206,33 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
     if (lane == 0) comp[chunk] = f;
 }
 
-// One wave walks the chunks in order carrying the exact f32 running sum.  64 chunk composites
-// are taken at a time: an inclusive scan of function composition over the lanes gives the state
-// after every chunk of the batch at once, the first chunk that leaves the binade (or was built for
-// another one) is found with a ballot, summed element by element with real f32 adds, and the
-// scan restarts behind it.
+// One wave walks the chunks in order carrying the exact f32 running sum.  256 chunk composites
+// are taken at a time, four consecutive ones per lane: each lane composes its own four, an
+// inclusive scan of function composition over the lanes then gives the state after every chunk
+// of the batch at once.  The sum only grows (the elements are >= 0), so the first chunk that
+// leaves the binade (or was built for another one) is the first whose state fails the test: it
+// is found with a ballot, summed element by element with real f32 adds, and the scan restarts
+// behind it.
 template <int PASS>
 __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_t n,
                                                         StatsScalars *sc, const Composite *comp,
                                                         uint32_t nchunks, float std_mul) {
+    constexpr int G = 4;
+    constexpr uint32_t BATCH = 64u * G;
     const int lane = threadIdx.x;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
     float s = 0.0f;  // uniform across the wave
-    for (uint32_t base = 0; base < nchunks; base += 64) {
-        Composite mine;
-        mine.a0 = mine.a1 = 0;
-        mine.e = ST_NO_BINADE;
-        mine.pad = 0;
-        if (base + lane < nchunks) mine = comp[base + lane];
-        const uint32_t lim = min(64u, nchunks - base);
+    for (uint32_t base = 0; base < nchunks; base += BATCH) {
+        Composite mine[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const uint32_t ci = base + (uint32_t)lane * G + k;
+            mine[k].a0 = mine[k].a1 = 0;
+            mine[k].e = ST_NO_BINADE;
+            mine[k].pad = 0;
+            if (ci < nchunks) mine[k] = comp[ci];
+        }
+        const uint32_t lim = min(BATCH, nchunks - base);
         uint32_t pos = 0;
         while (pos < lim) {
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
@@ -232,17 +240,24 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
             const uint32_t S = (bits & 0x7FFFFFu) | 0x800000u;
             // composites of the chunks already consumed act as the identity; unusable ones
             // saturate so that everything from them on reads as "left the binade"
-            Composite f;
-            f.e = e_now;
-            f.pad = 0;
-            if ((uint32_t)lane < pos) {
-                f.a0 = f.a1 = 0;
-            } else if (e_now != ST_NO_BINADE && mine.e == e_now && (uint32_t)lane < lim) {
-                f.a0 = mine.a0;
-                f.a1 = mine.a1;
-            } else {
-                f.a0 = f.a1 = ST_SAT;
+            Composite p[G];  // p[k] = this lane's chunks 0..k composed
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const uint32_t ci = (uint32_t)lane * G + k;
+                Composite u;
+                u.e = e_now;
+                u.pad = 0;
+                if (ci < pos) {
+                    u.a0 = u.a1 = 0;
+                } else if (e_now != ST_NO_BINADE && mine[k].e == e_now && ci < lim) {
+                    u.a0 = mine[k].a0;
+                    u.a1 = mine[k].a1;
+                } else {
+                    u.a0 = u.a1 = ST_SAT;
+                }
+                p[k] = (k == 0) ? u : compose(p[k - 1], u);
             }
+            Composite f = p[G - 1];
             for (int off = 1; off < 64; off <<= 1) {
                 Composite g;
                 g.a0 = __shfl_up(f.a0, off, 64);
@@ -251,14 +266,33 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                 g.pad = 0;
                 if (lane >= off) f = compose(g, f);
             }
-            const uint32_t S_after = S + ((S & 1u) ? f.a1 : f.a0);
-            const bool ok = S_after < (1u << 24);
-            unsigned long long bad = ~__ballot(ok);
-            bad &= ~((1ull << pos) - 1ull);  // lanes before pos are not part of the question
-            if (lim < 64u) bad &= (1ull << lim) - 1ull;
-            const uint32_t first_bad = bad ? (uint32_t)__builtin_ctzll(bad) : lim;
+            Composite ex;  // everything before this lane's chunks
+            ex.a0 = __shfl_up(f.a0, 1, 64);
+            ex.a1 = __shfl_up(f.a1, 1, 64);
+            ex.e = e_now;
+            ex.pad = 0;
+            if (lane == 0) ex.a0 = ex.a1 = 0;
+            uint32_t S_after[G];
+            int first_k = G;  // first of this lane's chunks whose state left the binade
+#pragma unroll
+            for (int k = G - 1; k >= 0; --k) {
+                const Composite h = compose(ex, p[k]);
+                S_after[k] = S + ((S & 1u) ? h.a1 : h.a0);
+                if (!(S_after[k] < (1u << 24))) first_k = k;
+            }
+            const unsigned long long bad = __ballot(first_k < G);
+            uint32_t first_bad = lim;
+            if (bad) {
+                const int bl = __builtin_ctzll(bad);
+                const uint32_t fb =
+                    (uint32_t)bl * G + (uint32_t)__builtin_amdgcn_readlane(first_k, bl);
+                if (fb < first_bad) first_bad = fb;
+            }
             if (first_bad > pos) {
-                const uint32_t Sj = __builtin_amdgcn_readlane(S_after, first_bad - 1);
+                const uint32_t j = first_bad - 1, kk = j % G;
+                const uint32_t sel = kk == 0 ? S_after[0] : kk == 1 ? S_after[1]
+                                   : kk == 2 ? S_after[2] : S_after[3];
+                const uint32_t Sj = __builtin_amdgcn_readlane(sel, j / G);
                 s = __uint_as_float((bits & 0xFF800000u) | (Sj & 0x7FFFFFu));
             }
             if (first_bad < lim) {

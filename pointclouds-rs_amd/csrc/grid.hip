@@ -318,6 +318,9 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
 
 // ----------------------------------------------------------------------------- query kernel
 
+// bit 31 of a retry-list entry: "not tried yet, just too crowded for one lane"
+constexpr uint32_t PCRS_HEAVY_FLAG = 0x80000000u;
+
 struct CellArgs {
     GridGeom g;
     const uint32_t *cell_start;
@@ -336,7 +339,9 @@ struct CellArgs {
     const uint32_t *qlist;
     const uint32_t *qcount;
     int R;                  // cube half-width in cells (per-lane kernels)
-    int wave_radii[3];      // cube half-widths the wave-per-query kernel tries in turn
+    int wave_radii[4];      // cube half-widths the wave-per-query kernel tries in turn; entry 0
+                            // is only for queries flagged PCRS_HEAVY_FLAG in the list
+    uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
     uint32_t kcert;         // neighbours that must be certified (<= K)
@@ -571,7 +576,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 
 // Wave-cooperative walk over the rows of a box of cells: f(p, valid, slot) is called by the whole
 // wave for every 64-point piece of every row.  The lanes first fetch the row ranges in parallel
-// (one memory latency for up to 64 rows), then the points of four rows are requested before any
+// (one memory latency for up to 64 rows), then the points of eight rows are requested before any
 // is used: a retried query is a single wave, so nothing else hides its load latency.
 template <class F>
 __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int y0, int y1, int z0,
@@ -598,24 +603,22 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
             }
         };
         int i = 0;
-        for (; i + 3 < cnt; i += 4) {
-            const uint32_t b0 = __builtin_amdgcn_readlane(ms0, i), e0 = __builtin_amdgcn_readlane(ms1, i);
-            const uint32_t b1 = __builtin_amdgcn_readlane(ms0, i + 1), e1 = __builtin_amdgcn_readlane(ms1, i + 1);
-            const uint32_t b2 = __builtin_amdgcn_readlane(ms0, i + 2), e2 = __builtin_amdgcn_readlane(ms1, i + 2);
-            const uint32_t b3 = __builtin_amdgcn_readlane(ms0, i + 3), e3 = __builtin_amdgcn_readlane(ms1, i + 3);
-            const bool v0 = b0 + lane < e0, v1 = b1 + lane < e1, v2 = b2 + lane < e2, v3 = b3 + lane < e3;
-            const float4 p0 = v0 ? a.spts[b0 + lane] : zero;
-            const float4 p1 = v1 ? a.spts[b1 + lane] : zero;
-            const float4 p2 = v2 ? a.spts[b2 + lane] : zero;
-            const float4 p3 = v3 ? a.spts[b3 + lane] : zero;
-            f(p0, v0, b0 + lane);
-            tail(b0, e0);
-            f(p1, v1, b1 + lane);
-            tail(b1, e1);
-            f(p2, v2, b2 + lane);
-            tail(b2, e2);
-            f(p3, v3, b3 + lane);
-            tail(b3, e3);
+        for (; i + 7 < cnt; i += 8) {
+            uint32_t b[8], e[8];
+            bool v[8];
+            float4 p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                b[j] = __builtin_amdgcn_readlane(ms0, i + j);
+                e[j] = __builtin_amdgcn_readlane(ms1, i + j);
+                v[j] = b[j] + lane < e[j];
+                p[j] = v[j] ? a.spts[b[j] + lane] : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f(p[j], v[j], b[j] + lane);
+                tail(b[j], e[j]);
+            }
         }
         for (; i < cnt; ++i) {
             const uint32_t b0 = __builtin_amdgcn_readlane(ms0, i), e0 = __builtin_amdgcn_readlane(ms1, i);
@@ -644,7 +647,9 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (uint32_t pos = blockIdx.x * WAVES + w; pos < total; pos += gridDim.x * WAVES) {
-        const uint32_t qi = a.qlist[pos];
+        const uint32_t entry = a.qlist[pos];
+        const uint32_t qi = entry & ~PCRS_HEAVY_FLAG;
+        const int first_radius = (entry & PCRS_HEAVY_FLAG) ? 0 : 1;
         const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];  // finite: stage 1 filtered
         const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
         const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
@@ -652,25 +657,47 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
         float D[K];
+        uint64_t best1 = PCRS_EMPTY_KEY;  // K == 1: key of the nearest point
         bool certified = false;
         // larger and larger cubes until the K-th distance is certified (the wave is uniform
         // in the query, so the escalation costs no divergence)
 #pragma unroll 1
-        for (int ri = 0; ri < 3 && !certified; ++ri) {
+        for (int ri = first_radius; ri < 4 && !certified; ++ri) {
             const int R = a.wave_radii[ri];
             x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
             y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
             z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
 #pragma unroll
             for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
+            best1 = PCRS_EMPTY_KEY;
             wave_walk(a, x0, x1, y0, y1, z0, z1, lane, [&](const float4 &p, bool valid, uint32_t) {
                 if (valid) {
                     const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+                    if constexpr (K == 1) {  // one neighbour: carry its identity along
+                        if (d2 <= D[0]) {
+                            const uint64_t k = make_key(d2, __float_as_uint(p.w));
+                            if (k < best1) {
+                                best1 = k;
+                                D[0] = d2;
+                            }
+                        }
+                    } else {
 #pragma unroll
-                    for (int t = K - 1; t > 0; --t) D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
-                    D[0] = fminf(D[0], d2);
+                        for (int t = K - 1; t > 0; --t)
+                            D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
+                        D[0] = fminf(D[0], d2);
+                    }
                 }
             });
+            if constexpr (K == 1) {
+                for (int r = 1; r < 64; r <<= 1) {
+                    const uint32_t lo = __shfl_xor((uint32_t)best1, r, 64);
+                    const uint32_t hi = __shfl_xor((uint32_t)(best1 >> 32), r, 64);
+                    const uint64_t other = ((uint64_t)hi << 32) | lo;
+                    if (other < best1) best1 = other;
+                }
+                D[0] = key_d2(best1);
+            } else {
             // butterfly merge of the 64 per-lane lists
 #pragma unroll 1
             for (int r = 1; r < 64; r <<= 1) {
@@ -685,6 +712,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
                         D[t] = __builtin_amdgcn_fmed3f(v, D[t - 1], D[t]);
                     D[0] = fminf(D[0], v);
                 }
+            }
             }
             const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
                                (z0 == 0) && (z1 == g.nz - 1);
@@ -713,7 +741,11 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         bool failed = !certified;
 
         uint32_t have = 0;
-        if (!failed && COLLECT) {
+        if (!failed && COLLECT && K == 1) {
+            if (lane == 0) wl_key[w][0] = best1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            have = best1 != PCRS_EMPTY_KEY ? 1u : 0u;
+        } else if (!failed && COLLECT) {
             float tau = __builtin_inff();
 #pragma unroll
             for (int i = 0; i < K; ++i)
@@ -803,37 +835,110 @@ __global__ __launch_bounds__(GB_THREADS) void owned_slots_kernel(const float4 *s
     if (own) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = s;
 }
 
-// 1-NN variant: a single pass tracking the best (d2, index) key.
+// 1-NN variant: a single pass tracking the best (d2, index) key, EIGHT LANES PER QUERY.  The
+// clouds this serves (ICP correspondences, ~1e5 queries) give a lane-per-query kernel barely one
+// wave per SIMD, each a long chain of dependent loads; eight lanes share the query's candidate
+// list (coalesced 128-byte reads), which makes eight times the waves and an eighth of the chain.
+constexpr int NN_SUB = 8;
+
 __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut out) {
     uint32_t total = a.nq;
     if (a.qmode == 2) total = *a.qcount;
     const GridGeom &g = a.g;
-    for (uint32_t pos = blockIdx.x * GB_THREADS + threadIdx.x; pos < total;
-         pos += gridDim.x * GB_THREADS) {
-        const uint32_t qi = (a.qmode == 2) ? a.qlist[pos] : pos;
-        const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];
-        if (!finite3(qx, qy, qz)) {
-            out.nn_idx[qi] = PCRS_NO_INDEX;
-            if (out.nn_d2) out.nn_d2[qi] = __builtin_inff();
-            continue;
+    const uint32_t sub = threadIdx.x & (NN_SUB - 1);
+    const uint32_t groups_per_grid = gridDim.x * (GB_THREADS / NN_SUB);
+    // the loop bound is the same for all lanes of a wave: the shuffles below need them all
+    for (uint32_t q0 = (blockIdx.x * GB_THREADS + (threadIdx.x & ~63u)) / NN_SUB; q0 < total;
+         q0 += groups_per_grid) {
+        const uint32_t qpos = q0 + ((threadIdx.x & 63u) / NN_SUB);
+        const bool active = qpos < total;
+        const uint32_t qi = active ? ((a.qmode == 2) ? a.qlist[qpos] : qpos) : 0u;
+        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+        if (active) {
+            qx = a.qx[qi];
+            qy = a.qy[qi];
+            qz = a.qz[qi];
         }
+        const bool qvalid = active && finite3(qx, qy, qz);
         const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
         const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
         const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
         const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+        // the nine row ranges of the cube, all requested together
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        uint32_t rb[9], re[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int yy = cy + i % 3 - 1, zz = cz + i / 3 - 1;
+            rb[i] = 0;
+            re[i] = 0;
+            if (qvalid && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                rb[i] = a.cell_start[row + x0];
+                re[i] = a.cell_start[row + x1 + 1];
+            }
+        }
+        // the ranges read as one list: start[i] = list position of row i, off[i] maps a list
+        // position inside row i to its sorted slot
+        uint32_t off[9], start[9], total_pts = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            start[i] = total_pts;
+            off[i] = rb[i] - total_pts;
+            total_pts += re[i] - rb[i];
+        }
+        // A crowded cube (a dense spot of the cloud) goes to the wave-per-query kernel, flagged
+        // so that that kernel starts with this same cube.
+        const bool diverted = qvalid && total_pts > a.heavy && a.fail_list != nullptr;
+        if (diverted) total_pts = 0;
+
         uint64_t best = PCRS_EMPTY_KEY;
         float best_d2 = __builtin_inff();
-        walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t) {
-            const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
-            if (d2 <= best_d2) {
-                const uint64_t k = make_key(d2, __float_as_uint(p.w));
-                if (k < best) {
-                    best = k;
-                    best_d2 = d2;
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t t0 = sub; t0 < total_pts; t0 += 4 * NN_SUB) {
+            float4 p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = t0 + j * NN_SUB;
+                uint32_t o = off[0];
+#pragma unroll
+                for (int i = 1; i < 9; ++i) o = (t >= start[i]) ? off[i] : o;
+                p[j] = (t < total_pts) ? a.spts[t + o] : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (t0 + j * NN_SUB < total_pts) {
+                    const float d2 = sqdist(qx, qy, qz, p[j].x, p[j].y, p[j].z);
+                    if (d2 <= best_d2) {
+                        const uint64_t k = make_key(d2, __float_as_uint(p[j].w));
+                        if (k < best) {
+                            best = k;
+                            best_d2 = d2;
+                        }
+                    }
                 }
             }
-        });
-        const int R = a.R;
+        }
+#pragma unroll
+        for (int r = 1; r < NN_SUB; r <<= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)best, r, 64);
+            const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), r, 64);
+            const uint64_t other = ((uint64_t)hi << 32) | lo;
+            if (other < best) best = other;
+        }
+        best_d2 = key_d2(best);
+        if (sub != 0 || !active) continue;  // after the shuffles: one lane finishes the query
+        if (!qvalid) {
+            out.nn_idx[qi] = PCRS_NO_INDEX;
+            if (out.nn_d2) out.nn_d2[qi] = __builtin_inff();
+            continue;
+        }
+        if (diverted) {
+            const uint32_t f = atomicAdd(a.fail_count, 1u);
+            a.fail_list[f] = qi | PCRS_HEAVY_FLAG;
+            continue;
+        }
+        const int R = 1;
         const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
                            (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
         bool certified = whole;
@@ -1230,9 +1335,9 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     const int kb = k_bucket(keff);
 
     auto launch = [&](unsigned blocks) {
-        if (nn_only) {
-            hipLaunchKernelGGL(nn_cell_kernel, dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a,
-                               out);
+        if (nn_only) {  // eight lanes per query
+            hipLaunchKernelGGL(nn_cell_kernel, dim3(blocks * NN_SUB), dim3(GB_THREADS), 0,
+                               ctx->stream, a, out);
             return;
         }
 #define PCRS_CELL_CALL(KK)                                                                      \
@@ -1250,6 +1355,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
 
     // stage 1: the 27-cell cube over every query
     a.R = 1;
+    a.heavy = nq < PCRS_HEAVY_FLAG ? 2048u : 0xFFFFFFFFu;  // the flag needs bit 31 of the entry
     a.fail_list = listA;
     a.fail_count = &counters[0];
     unsigned blocks1 = (unsigned)((nq + GB_THREADS - 1) / GB_THREADS);
@@ -1302,9 +1408,10 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     };
     const unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);
     // one launch tries the cube half-widths 2, 4, 8 in turn for each failed query
-    a.wave_radii[0] = 2;
-    a.wave_radii[1] = 4;
-    a.wave_radii[2] = 8;
+    a.wave_radii[0] = 1;
+    a.wave_radii[1] = 2;
+    a.wave_radii[2] = 4;
+    a.wave_radii[3] = 8;
     a.qmode = 2;
     a.qlist = listA;
     a.qcount = &counters[0];

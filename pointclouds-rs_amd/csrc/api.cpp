@@ -729,6 +729,7 @@ struct pcrs_icp {
     // source in the cell order of a grid over itself (neighbouring lanes then search neighbouring
     // target cells); perm[i] = original index of sorted point i, empty = original order kept
     DevBuf ord_s[3], perm;
+    DevBuf state;  // IcpLoopState of pcrs_icp_run
 };
 
 namespace {
@@ -789,6 +790,7 @@ int icp_alloc_work(pcrs_icp *icp) {
     PCRS_HIP_CHECK(ctx, icp->nn_idx.alloc(n * sizeof(uint32_t)));
     PCRS_HIP_CHECK(ctx, icp->nn_d2.alloc(n * sizeof(float)));
     PCRS_HIP_CHECK(ctx, icp->sums.alloc(PCRS_ICP_NSUMS * sizeof(double)));
+    PCRS_HIP_CHECK(ctx, icp->state.alloc(sizeof(IcpLoopState)));
     return PCRS_OK;
 }
 
@@ -1031,45 +1033,52 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
         return PCRS_OK;
     }
     PCRS_TRY(pcrs_icp_reset(icp));
-    float cum_r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, cum_t[3] = {0, 0, 0};
-    float prev_rmse = std::numeric_limits<float>::infinity();
-    float last_rmse = std::numeric_limits<float>::infinity();
-    float last_fitness = 0.0f;
-    bool converged = false;
-    uint32_t num_iterations = 0;
-    double sums[PCRS_ICP_NSUMS];
-    auto metrics = [&](float *rmse, float *fitness) {
-        *rmse = (float)std::sqrt(sums[1] / sums[0]);           // icp.rs:273-282
-        *fitness = (float)(size_t)sums[0] / (float)icp->n;     // icp.rs:170
-    };
-    for (uint32_t iter = 0; iter < max_iterations; ++iter) {
-        num_iterations = iter + 1;
+    if (max_iterations == 0) {  // icp.rs:190-197: one metrics pass, identity transform
+        double sums[PCRS_ICP_NSUMS];
         PCRS_TRY(pcrs_icp_accumulate(icp, mode, max_correspondence_distance, sums));
-        if (!(sums[0] > 0.0)) break;  // icp.rs:163-165
-        float rmse, fitness;
-        metrics(&rmse, &fitness);
-        last_rmse = rmse;
-        last_fitness = fitness;
-        if (std::fabs(prev_rmse - rmse) < tolerance) {  // icp.rs:173-176
-            converged = true;
-            break;
+        out->rmse = std::numeric_limits<float>::infinity();
+        if (sums[0] > 0.0) {
+            out->rmse = (float)std::sqrt(sums[1] / sums[0]);       // icp.rs:273-282
+            out->fitness = (float)(size_t)sums[0] / (float)icp->n;  // icp.rs:170
         }
-        prev_rmse = rmse;
-        float inc_r[9], inc_t[3];
-        PCRS_TRY(pcrs_icp_solve(mode, sums, inc_r, inc_t));
-        pcrs_host_compose(cum_r, cum_t, inc_r, inc_t, cum_r, cum_t);  // icp.rs:183
-        PCRS_TRY(pcrs_icp_apply(icp, inc_r, inc_t));                  // icp.rs:186
+        return PCRS_OK;
     }
-    if (num_iterations == 0) {  // icp.rs:190-197
-        PCRS_TRY(pcrs_icp_accumulate(icp, mode, max_correspondence_distance, sums));
-        if (sums[0] > 0.0) metrics(&last_rmse, &last_fitness);
+    // The loop state lives on the device (icp_tail_kernel carries icp.rs:147-188), so the host
+    // only looks at it every few iterations; iterations queued behind the end of the loop are
+    // no-ops.
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState), &pin));
+    IcpLoopState *hs = reinterpret_cast<IcpLoopState *>(pin);
+    std::memset(hs, 0, sizeof(*hs));
+    hs->cum_r[0] = hs->cum_r[4] = hs->cum_r[8] = 1.0f;
+    hs->inc_r[0] = hs->inc_r[4] = hs->inc_r[8] = 1.0f;
+    hs->prev_rmse = hs->last_rmse = std::numeric_limits<float>::infinity();
+    IcpLoopState *ds = icp->state.as<IcpLoopState>();
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, sizeof(*hs), hipMemcpyHostToDevice, ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // hs is reused for the read-backs
+    float *cx = icp->cur[0].as<float>(), *cy = icp->cur[1].as<float>(), *cz = icp->cur[2].as<float>();
+    constexpr uint32_t kBatch = 4;
+    for (uint32_t iter = 0; iter < max_iterations;) {
+        const uint32_t nb = std::min(kBatch, max_iterations - iter);
+        for (uint32_t j = 0; j < nb; ++j) {
+            PCRS_TRY(correspond_and_reduce(ctx, icp->target, mode, cx, cy, cz, icp->n, icp->tnx,
+                                           icp->tny, icp->tnz, max_correspondence_distance,
+                                           icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
+                                           icp->sums.as<double>(), nullptr, nullptr));
+            PCRS_TRY(pcrs_launch_icp_tail(ctx, mode, icp->sums.as<double>(), icp->n, tolerance, ds));
+            PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));  // icp.rs:186
+        }
+        iter += nb;
+        PCRS_TRY(download(ctx, hs, ds, sizeof(*hs)));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (hs->done) break;
     }
-    std::memcpy(out->rotation, cum_r, sizeof(cum_r));
-    std::memcpy(out->translation, cum_t, sizeof(cum_t));
-    out->fitness = last_fitness;
-    out->rmse = last_rmse;
-    out->converged = converged ? 1 : 0;
-    out->num_iterations = num_iterations;
+    std::memcpy(out->rotation, hs->cum_r, sizeof(hs->cum_r));
+    std::memcpy(out->translation, hs->cum_t, sizeof(hs->cum_t));
+    out->fitness = hs->last_fitness;
+    out->rmse = hs->last_rmse;
+    out->converged = hs->converged ? 1 : 0;
+    out->num_iterations = hs->num_iterations;
     return PCRS_OK;
 }
 

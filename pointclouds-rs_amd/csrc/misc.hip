@@ -1,6 +1,7 @@
 // Streaming kernels around the neighbour search: inlier mask, rigid transform, radius count and
 // the ICP consumer reduction.  All are HBM-bound single passes over SoA columns.
 #include "knn_common.h"
+#include "solve_math.h"
 
 #pragma clang fp contract(off)
 
@@ -274,6 +275,79 @@ int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, co
     const float r2 = radius * radius;  // kdtree.rs:114
     hipLaunchKernelGGL(radius_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        ctx->stream, rx, ry, rz, (uint32_t)m, qx, qy, qz, (uint32_t)n, r2, count);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident ICP loop: one thread does what the host does between two iterations.
+namespace pcrs {
+
+__global__ void icp_tail_kernel(int mode, const double *sums, float n_source, float tolerance,
+                                IcpLoopState *st) {
+    if (st->done) return;
+    st->num_iterations += 1u;
+    if (!(sums[0] > 0.0)) {  // icp.rs:163-165
+        st->done = 1u;
+        return;
+    }
+    const float rmse = (float)sqrt(sums[1] / sums[0]);          // icp.rs:273-282
+    const float fitness = (float)(size_t)sums[0] / n_source;    // icp.rs:170
+    st->last_rmse = rmse;
+    st->last_fitness = fitness;
+    if (fabsf(st->prev_rmse - rmse) < tolerance) {  // icp.rs:173-176
+        st->converged = 1u;
+        st->done = 1u;
+        return;
+    }
+    st->prev_rmse = rmse;
+    float r[9], t[3];
+    if (mode == PCRS_ICP_POINT_TO_PLANE)
+        pcrs_math::solve_plane(sums, r, t);
+    else
+        pcrs_math::solve_point(sums, r, t);
+    for (int i = 0; i < 9; ++i) st->inc_r[i] = r[i];
+    for (int i = 0; i < 3; ++i) st->inc_t[i] = t[i];
+    float cr[9], ct[3], nr[9], nt[3];
+    for (int i = 0; i < 9; ++i) cr[i] = st->cum_r[i];
+    for (int i = 0; i < 3; ++i) ct[i] = st->cum_t[i];
+    pcrs_math::compose(cr, ct, r, t, nr, nt);  // icp.rs:183
+    for (int i = 0; i < 9; ++i) st->cum_r[i] = nr[i];
+    for (int i = 0; i < 3; ++i) st->cum_t[i] = nt[i];
+}
+
+__global__ __launch_bounds__(256) void transform_state_kernel(float *x, float *y, float *z, size_t n,
+                                                              const IcpLoopState *st) {
+    if (st->done) return;
+    float r[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = st->inc_r[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = st->inc_t[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float px = x[i], py = y[i], pz = z[i];
+        x[i] = ((r[0] * px + r[1] * py) + r[2] * pz) + t[0];
+        y[i] = ((r[3] * px + r[4] * py) + r[5] * pz) + t[1];
+        z[i] = ((r[6] * px + r[7] * py) + r[8] * pz) + t[2];
+    }
+}
+
+}  // namespace pcrs
+
+int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, size_t n_source,
+                         float tolerance, IcpLoopState *d_state) {
+    hipLaunchKernelGGL(pcrs::icp_tail_kernel, dim3(1), dim3(1), 0, ctx->stream, mode, d_sums,
+                       (float)n_source, tolerance, d_state);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_transform_state(pcrs_ctx *ctx, float *x, float *y, float *z, size_t n,
+                                const IcpLoopState *d_state) {
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(pcrs::transform_state_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                       ctx->stream, x, y, z, n, d_state);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

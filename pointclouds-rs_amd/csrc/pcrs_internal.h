@@ -200,6 +200,22 @@ int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, co
                              float radius, uint32_t *count);
 // ICP consumer reduction over dense correspondences (nn_idx / nn_d2 per source point).
 // partials: device scratch of PCRS_ICP_NSUMS doubles per block; result in d_sums[PCRS_ICP_NSUMS].
+// Loop state of an ICP run that lives on the device, so that several iterations can be queued
+// without a host round trip (icp.rs:147-188 is the loop it carries).
+struct IcpLoopState {
+    float cum_r[9], cum_t[3];  // accumulated transform
+    float inc_r[9], inc_t[3];  // increment solved by the last live iteration
+    float prev_rmse, last_rmse, last_fitness;
+    uint32_t converged;
+    uint32_t done;  // loop has ended (converged or no correspondences): later iterations are no-ops
+    uint32_t num_iterations;
+};
+// After the sums of an iteration are in d_sums: metrics, convergence test, solve, compose.
+int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, size_t n_source,
+                         float tolerance, IcpLoopState *d_state);
+// cur = inc(cur) with the increment read from the device state; no-op once the loop is done.
+int pcrs_launch_transform_state(pcrs_ctx *ctx, float *x, float *y, float *z, size_t n,
+                                const IcpLoopState *d_state);
 int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float *cy,
                            const float *cz, size_t n, const float *tx, const float *ty,
                            const float *tz, const float *tnx, const float *tny, const float *tnz,

@@ -119,6 +119,20 @@ int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const
 int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
                           size_t n, float radius, uint32_t *dcount);
 
+/* radius_outlier_removal — crates/filters/src/radius_outlier.rs:4-18: keep[i] = 1
+ * when at least min_neighbors points of the cloud (point i itself included) lie
+ * within `radius` of point i.  As in KdTree::radius_search (kdtree.rs:105-135) a
+ * non-positive or non-finite radius, or a non-finite point, finds nothing, so such
+ * points are kept only when min_neighbors == 0.  count (nullable) receives the
+ * per-point neighbour counts; the caller gathers the kept rows (cloud.rs:103-162).
+ * The _dev variant takes device pointers and synchronises only to return n_keep. */
+int pcrs_radius_outlier(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                        float radius, size_t min_neighbors, uint8_t *keep, uint32_t *count,
+                        size_t *n_keep);
+int pcrs_radius_outlier_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                            size_t n, float radius, size_t min_neighbors, uint8_t *dkeep,
+                            uint32_t *dcount, size_t *n_keep);
+
 /* ------------------------------------------- statistical_outlier_removal */
 
 /* The per-point loop of statistical_outlier_removal —

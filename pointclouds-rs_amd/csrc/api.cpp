@@ -394,8 +394,103 @@ int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy,
     if (!index || !dcount) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
+    // kdtree.rs:106-112: radius <= 0 or non-finite -> no results (the brute-force launcher
+    // handles those); otherwise the grid counts when the ball fits a small cube of cells
+    const bool usable = radius > 0.0f && radius - radius == 0.0f;
+    if (n && usable && pcrs_grid_radius_ok(index, radius)) {
+        if (!dqx || !dqy || !dqz)
+            return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+        KnnQuery q;
+        q.qx = dqx;
+        q.qy = dqy;
+        q.qz = dqz;
+        q.nq = n;
+        return pcrs_launch_radius_count_grid(index, q, radius, dcount);
+    }
     return pcrs_launch_radius_count(ctx, index->x, index->y, index->z, index->m, dqx, dqy, dqz, n,
                                     radius, dcount);
+}
+
+// radius_outlier.rs:4-18 on device columns: grid with cells of the radius, one counting walk,
+// mask.  dcount (nullable) receives the per-point neighbour counts.
+int pcrs_radius_outlier_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                            size_t n, float radius, size_t min_neighbors, uint8_t *dkeep,
+                            uint32_t *dcount, size_t *n_keep) {
+    PCRS_TRY(bind_device(ctx));
+    if (n_keep) *n_keep = 0;
+    if (n == 0) return PCRS_OK;
+    if (!dx || !dy || !dz || !dkeep) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    if (n >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    DevBuf own_count;
+    if (!dcount) {
+        PCRS_HIP_CHECK(ctx, own_count.alloc(ctx, n * sizeof(uint32_t)));
+        dcount = own_count.as<uint32_t>();
+    }
+    const bool usable = radius > 0.0f && radius - radius == 0.0f;
+    pcrs_index *ix = new (std::nothrow) pcrs_index();
+    if (!ix) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    ix->ctx = ctx;
+    ix->x = dx;
+    ix->y = dy;
+    ix->z = dz;
+    ix->m = n;
+    ix->algo = PCRS_ALGO_BRUTE;
+    int rc = PCRS_OK;
+    if (usable && n >= kGridMinPoints) rc = pcrs_grid_build(ix, 0, radius);
+    if (rc == PCRS_OK) {
+        // a grid of a few cells would make every lane scan most of the cloud on its own: the
+        // tiled brute-force scan is the better kernel there
+        if (usable && ix->ncell > 100 && pcrs_grid_radius_ok(ix, radius)) {
+            KnnQuery q;
+            q.nq = n;
+            q.self = true;
+            rc = pcrs_launch_radius_count_grid(ix, q, radius, dcount);
+        } else {
+            rc = pcrs_launch_radius_count(ctx, dx, dy, dz, n, dx, dy, dz, n, radius, dcount);
+        }
+    }
+    unsigned long long *dtotal = nullptr, *htotal = nullptr;
+    if (rc == PCRS_OK && n_keep) {
+        void *p = nullptr, *sc = nullptr;
+        rc = pcrs_ctx_pinned(ctx, 64, &p);
+        if (rc == PCRS_OK) rc = pcrs_ctx_scratch(ctx, 64, &sc);
+        htotal = reinterpret_cast<unsigned long long *>(p);
+        dtotal = reinterpret_cast<unsigned long long *>(sc);
+    }
+    if (rc == PCRS_OK) rc = pcrs_launch_count_mask(ctx, dcount, n, min_neighbors, dkeep, dtotal);
+    if (rc == PCRS_OK && n_keep) {
+        rc = download(ctx, htotal, dtotal, sizeof(unsigned long long));
+        if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed");
+        if (rc == PCRS_OK) *n_keep = (size_t)*htotal;
+    }
+    pcrs_index_destroy(ix);
+    return rc;
+}
+
+int pcrs_radius_outlier(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                        float radius, size_t min_neighbors, uint8_t *keep, uint32_t *count,
+                        size_t *n_keep) {
+    PCRS_TRY(bind_device(ctx));
+    if (n_keep) *n_keep = 0;
+    if (n == 0) return PCRS_OK;
+    if (!x || !y || !z || !keep) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    DevBuf dx, dy, dz, dkeep, dcount;
+    PCRS_TRY(upload(ctx, dx, x, n));
+    PCRS_TRY(upload(ctx, dy, y, n));
+    PCRS_TRY(upload(ctx, dz, z, n));
+    PCRS_HIP_CHECK(ctx, dkeep.alloc(n));
+    PCRS_HIP_CHECK(ctx, dcount.alloc(n * sizeof(uint32_t)));
+    size_t kept = 0;
+    PCRS_TRY(pcrs_radius_outlier_dev(ctx, dx.as<float>(), dy.as<float>(), dz.as<float>(), n, radius,
+                                     min_neighbors, dkeep.as<uint8_t>(), dcount.as<uint32_t>(),
+                                     &kept));
+    PCRS_TRY(download(ctx, keep, dkeep.p, n));
+    if (count) PCRS_TRY(download(ctx, count, dcount.p, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_keep) *n_keep = kept;
+    return PCRS_OK;
 }
 
 int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const float *qz,

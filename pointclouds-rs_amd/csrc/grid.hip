@@ -969,6 +969,41 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
     }
 }
 
+// Number of indexed points within sqrt(r2) of each query (kdtree.rs:114-129: d2 <= r2, the query
+// itself included when it is in the cloud): the cube of a.R cells around the query's cell covers
+// the ball, so one walk counts exactly.  qmode 0 (every sorted slot, output at the point's
+// original index) or 1 (explicit queries).
+__global__ __launch_bounds__(GB_THREADS) void radius_cell_kernel(CellArgs a, float r2,
+                                                                 uint32_t *count) {
+    const GridGeom &g = a.g;
+    for (uint32_t pos = blockIdx.x * GB_THREADS + threadIdx.x; pos < a.nq;
+         pos += gridDim.x * GB_THREADS) {
+        uint32_t qi = pos;
+        float qx, qy, qz;
+        if (a.qmode == 0) {
+            const float4 p = a.spts[pos];
+            qi = __float_as_uint(p.w);
+            qx = p.x;
+            qy = p.y;
+            qz = p.z;
+        } else {
+            qx = a.qx[qi];
+            qy = a.qy[qi];
+            qz = a.qz[qi];
+        }
+        uint32_t c = 0;
+        if (finite3(qx, qy, qz)) {
+            const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
+            const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
+            const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+            walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t) {
+                c += (sqdist(qx, qy, qz, p.x, p.y, p.z) <= r2) ? 1u : 0u;
+            });
+        }
+        count[qi] = c;
+    }
+}
+
 // Puts the points of every cell into ascending original-index order (one thread per cell; the
 // scatter's atomics leave them in arrival order).  Used where a reproducible point order matters.
 __global__ __launch_bounds__(GB_THREADS) void sort_cells_kernel(const uint32_t *cell_start,
@@ -1110,7 +1145,7 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
 
 }  // namespace
 
-int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
+int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     pcrs_ctx *ctx = ix->ctx;
     const uint32_t m = (uint32_t)ix->m;
     ix->algo = PCRS_ALGO_BRUTE;
@@ -1154,6 +1189,9 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
     double eff[3];
     for (int a = 0; a < 3; ++a) eff[a] = ext[a] > 1e-3 * emax ? ext[a] : 1e-3 * emax;
     double cell = cbrt(eff[0] * eff[1] * eff[2] * P / (double)nvalid);
+    // a radius search wants cells of the radius (one attempt, no occupancy feedback)
+    const bool fixed_cell = cell_request > 0.0f && cell_request < 1e30f;
+    if (fixed_cell) cell = (double)cell_request;
     const double max_cells = 4.0 * (double)nvalid + 4096.0;
     GridGeom g{};
     uint32_t ncell = 0;
@@ -1205,7 +1243,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint) {
                                d_nonempty);
         }
         sorted_done = two_level;
-        if (attempt == 3) break;
+        if (attempt == 3 || fixed_cell) break;
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_nonempty, d_nonempty, sizeof(uint32_t),
                                            hipMemcpyDeviceToHost, ctx->stream));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1279,6 +1317,50 @@ int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, ui
     const uint32_t n = (uint32_t)ix->nvalid;
     hipLaunchKernelGGL(unpack_sorted_kernel, dim3((n + GB_THREADS - 1) / GB_THREADS),
                        dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(), n, ox, oy, oz, perm);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// Cube half-width (cells) that is certain to cover a ball of the given radius around any query,
+// with the same allowance for f32 cell assignment as the neighbour-search certification.
+static int radius_cells(const pcrs_index *ix, float radius) {
+    const GridGeom &g = ix->g;
+    const double extent = (double)std::max(g.nx, std::max(g.ny, g.nz)) * (double)g.cell;
+    const double need = (double)radius * (1.0 + 1e-5) + (double)g.slack + 4e-6 * extent;
+    const double rc = std::ceil(need / (double)g.cell);
+    return rc > 1e6 ? 1000000 : (int)rc;
+}
+
+bool pcrs_grid_radius_ok(const pcrs_index *ix, float radius) {
+    return ix->algo == PCRS_ALGO_GRID && ix->nvalid > 0 && radius_cells(ix, radius) <= 3;
+}
+
+int pcrs_launch_radius_count_grid(pcrs_index *ix, const KnnQuery &q, float radius,
+                                  uint32_t *count) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (q.nq == 0) return PCRS_OK;
+    CellArgs a{};
+    a.g = ix->g;
+    a.cell_start = ix->cell_start.as<uint32_t>();
+    a.spts = ix->spts.as<float4>();
+    a.nvalid = (uint32_t)ix->nvalid;
+    a.R = radius_cells(ix, radius);
+    const float r2 = radius * radius;  // kdtree.rs:114
+    uint32_t nq = (uint32_t)q.nq;
+    if (q.self) {  // the whole cloud, in sorted-slot order; non-finite points count nothing
+        if (ix->nvalid < ix->m)
+            PCRS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, ix->m * sizeof(uint32_t), ctx->stream));
+        a.qmode = 0;
+        nq = (uint32_t)ix->nvalid;
+    } else {
+        a.qmode = 1;
+        a.qx = q.qx;
+        a.qy = q.qy;
+        a.qz = q.qz;
+    }
+    a.nq = nq;
+    hipLaunchKernelGGL(radius_cell_kernel, dim3((nq + GB_THREADS - 1) / GB_THREADS),
+                       dim3(GB_THREADS), 0, ctx->stream, a, r2, count);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

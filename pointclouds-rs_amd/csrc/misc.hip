@@ -279,6 +279,35 @@ int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, co
     return PCRS_OK;
 }
 
+namespace pcrs {
+__global__ __launch_bounds__(256) void count_mask_kernel(const uint32_t *count, size_t n,
+                                                         unsigned long long min_neighbors,
+                                                         uint8_t *keep, unsigned long long *total) {
+    unsigned local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const bool k = (unsigned long long)count[i] >= min_neighbors;
+        keep[i] = k ? 1 : 0;
+        local += k ? 1u : 0u;
+    }
+    if (!total) return;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, (unsigned long long)local);
+}
+}  // namespace pcrs
+
+int pcrs_launch_count_mask(pcrs_ctx *ctx, const uint32_t *count, size_t n, size_t min_neighbors,
+                           uint8_t *keep, unsigned long long *d_count) {
+    if (d_count) PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(*d_count), ctx->stream));
+    if (n == 0) return PCRS_OK;
+    size_t blocks = (n + 1023) / 1024;
+    if (blocks > (size_t)ctx->num_cus) blocks = (size_t)ctx->num_cus;
+    hipLaunchKernelGGL(pcrs::count_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       count, n, (unsigned long long)min_neighbors, keep, d_count);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Device-resident ICP loop: one thread does what the host does between two iterations.
 namespace pcrs {

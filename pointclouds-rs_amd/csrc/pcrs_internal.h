@@ -178,7 +178,15 @@ int pcrs_launch_knn_bf(pcrs_ctx *ctx, const float *rx, const float *ry, const fl
                        const uint32_t *qlist, const uint32_t *qlist_count, size_t qlist_cap);
 
 // ---- grid (grid.hip)
-int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint);
+// cell_request > 0 fixes the cell edge (enlarged only if the cell budget demands it)
+int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request = 0.0f);
+// radius count over the grid: possible when the ball fits a cube of at most 7^3 cells
+bool pcrs_grid_radius_ok(const pcrs_index *ix, float radius);
+int pcrs_launch_radius_count_grid(pcrs_index *ix, const KnnQuery &q, float radius,
+                                  uint32_t *count);
+// keep[i] = count[i] >= min_neighbors (radius_outlier.rs:13)
+int pcrs_launch_count_mask(pcrs_ctx *ctx, const uint32_t *count, size_t n, size_t min_neighbors,
+                           uint8_t *keep, unsigned long long *d_count);
 // Writes the points in cell order (ties inside a cell by original index) as columns, with the
 // permutation sorted position -> original index.  Needs algo == GRID; all nvalid points.
 int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm);

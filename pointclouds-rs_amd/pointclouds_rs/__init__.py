@@ -155,12 +155,10 @@ def radius_outlier_removal(cloud, radius, min_neighbors):
         raise ValueError("radius must be > 0 and finite")
     if cloud.is_empty():
         return PointCloud()
-    ix = hip.Index(cloud._x, cloud._y, cloud._z)
-    try:
-        count = ix.radius_count(cloud._x, cloud._y, cloud._z, radius)
-    finally:
-        ix.close()
-    return cloud.select(np.nonzero(count >= int(min_neighbors))[0])
+    if min_neighbors < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    keep, _, _ = hip.radius_outlier(cloud._x, cloud._y, cloud._z, radius, int(min_neighbors))
+    return cloud.select(np.nonzero(keep)[0])
 
 
 def estimate_normals(cloud, k):

@@ -61,6 +61,10 @@ SIGNATURES = {
     "pcrs_knn_batch_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, _V, _V, _V]),
     "pcrs_radius_count": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V]),
     "pcrs_radius_count_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V]),
+    "pcrs_radius_outlier": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, _V, _V,
+                                                   c_size_p]),
+    "pcrs_radius_outlier_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, _V, _V,
+                                                       c_size_p]),
     "pcrs_sor_mean_dist_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, _V]),
     "pcrs_sor_threshold_dev": (C.c_int, [_V, _V, C.c_size_t, C.c_float, c_float_p, C.POINTER(C.c_int)]),
     "pcrs_sor_mask_dev": (C.c_int, [_V, _V, C.c_size_t, C.c_float, _V, c_size_p]),

@@ -125,6 +125,21 @@ def sor(x, y, z, k, std_mul, device=0):
     return keep.astype(bool), int(n_keep.value), float(thr.value), mean
 
 
+def radius_outlier(x, y, z, radius, min_neighbors, device=0):
+    """radius_outlier_removal on columns: (keep[n] bool, n_keep, count[n])."""
+    ctx = get_context(device)
+    x, y, z = _col(x), _col(y), _col(z)
+    n = len(x)
+    keep = np.zeros(n, dtype=np.uint8)
+    count = np.zeros(n, dtype=np.uint32)
+    n_keep = C.c_size_t(0)
+    ctx.check(
+        ctx.lib.pcrs_radius_outlier(ctx.handle, _ptr(x), _ptr(y), _ptr(z), n, float(radius),
+                                    int(min_neighbors), _ptr(keep), _ptr(count), C.byref(n_keep))
+    )
+    return keep.astype(bool), int(n_keep.value), count
+
+
 def normals(x, y, z, k, viewpoint=(0.0, 0.0, 0.0), device=0):
     """estimate_normals_with_viewpoint on columns: (nx, ny, nz); empty when k == 0."""
     ctx = get_context(device)

@@ -155,6 +155,40 @@ def test_radius_count_parity(hip, oracle):
     ix.close()
 
 
+def test_radius_count_grid_parity(hip, oracle):
+    """Grid-backed radius counts: cloud queries, queries outside the bounding box, radii from a
+    fraction of a cell to several cells (the largest falls back to the brute-force scan)."""
+    ux, uy, uz = gen.uniform_cloud(20000, 5, 0, 10)
+    dx, dy, dz = gen.degenerate_cloud(300, 9)
+    x, y, z = np.concatenate([ux, dx]), np.concatenate([uy, dy]), np.concatenate([uz, dz])
+    qx = np.concatenate([x[:3000], np.array([-5, 15, 5, np.nan], dtype=F)])
+    qy = np.concatenate([y[:3000], np.array([5, 5, -20, 1], dtype=F)])
+    qz = np.concatenate([z[:3000], np.array([5, 12, 5, 1], dtype=F)])
+    ix = hip.Index(x, y, z, k_hint=16, algo=2)
+    for r in (0.05, 0.4, 0.9, 1.7, 6.0):
+        c = ix.radius_count(qx, qy, qz, r)
+        d2 = ((qx[:, None].astype(F) - x[None, :]) ** 2 + (qy[:, None] - y[None, :]) ** 2) \
+            + (qz[:, None] - z[None, :]) ** 2
+        ref = (d2 <= F(r) * F(r)).sum(1).astype(np.uint32)  # NaN compares false
+        assert np.array_equal(c, ref), r
+    ix.close()
+
+
+@pytest.mark.parametrize("n", [500, 30000], ids=["brute", "grid"])
+def test_radius_outlier_parity(hip, oracle, n):
+    ux, uy, uz = gen.uniform_cloud(n, 21, 0, 20)
+    dx, dy, dz = gen.degenerate_cloud(300, 3)
+    x, y, z = np.concatenate([ux, dx]), np.concatenate([uy, dy]), np.concatenate([uz, dz])
+    for r, mn in ((0.8, 4), (1.5, 1), (0.02, 2), (50.0, 10), (1.0, 0), (-1.0, 1), (float("nan"), 0),
+                  (float("inf"), 1)):
+        keep, n_keep, count = hip.radius_outlier(x, y, z, r, mn)
+        rkeep, rn, rcount = oracle.radius_outlier(x, y, z, r, mn)
+        assert np.array_equal(count, rcount), (r, mn)
+        assert np.array_equal(keep, rkeep) and n_keep == rn, (r, mn)
+    keep, n_keep, count = hip.radius_outlier([], [], [], 1.0, 1)
+    assert len(keep) == 0 and n_keep == 0
+
+
 def test_apply_transform_bit_exact(hip, oracle):
     x, y, z = gen.uniform_cloud(10000, 4, -50, 50)
     R = gen.rot_z(0.3)

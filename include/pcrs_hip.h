@@ -133,6 +133,20 @@ int pcrs_radius_outlier_dev(pcrs_ctx *ctx, const float *dx, const float *dy, con
                             size_t n, float radius, size_t min_neighbors, uint8_t *dkeep,
                             uint32_t *dcount, size_t *n_keep);
 
+/* voxel_downsample — crates/filters/src/voxel_downsample.rs:12-65: one centroid per
+ * occupied voxel of edge voxel_size, in ascending (x, y, z) voxel-key order, each the
+ * f32 sum of the voxel's finite points taken in input order divided by their count
+ * (bit-identical to the reference).  out_x/out_y/out_z must hold n values; *n_out
+ * receives the number of voxels.  voxel_size must be > 0 and finite (the reference
+ * asserts it): PCRS_ERR_INVALID_ARG otherwise.  The _dev variant takes device pointers
+ * and returns after the centroids are complete. */
+int pcrs_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                          float voxel_size, float *out_x, float *out_y, float *out_z,
+                          size_t *n_out);
+int pcrs_voxel_downsample_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                              size_t n, float voxel_size, float *dout_x, float *dout_y,
+                              float *dout_z, size_t *n_out);
+
 /* ------------------------------------------- statistical_outlier_removal */
 
 /* The per-point loop of statistical_outlier_removal —

@@ -498,6 +498,74 @@ size_t orc_radius_outlier(const float *x, const float *y, const float *z, size_t
 }
 
 /* ------------------------------------------------------------------ */
+/* voxel_downsample (crates/filters/src/voxel_downsample.rs:12-65)     */
+/* ------------------------------------------------------------------ */
+
+/* Rust `f32 as i32`: saturating, NaN -> 0 */
+static int32_t sat_i32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+typedef struct {
+    int32_t k[3];
+    uint32_t idx;
+} voxel_entry;
+
+static int voxel_cmp(const void *pa, const void *pb) {
+    const voxel_entry *a = (const voxel_entry *)pa, *b = (const voxel_entry *)pb;
+    for (int i = 0; i < 3; ++i) {
+        if (a->k[i] < b->k[i]) return -1;
+        if (a->k[i] > b->k[i]) return 1;
+    }
+    return (a->idx > b->idx) - (a->idx < b->idx);
+}
+
+/* The reference accumulates every finite point into its voxel's bin in input order (:24-42)
+ * and emits the bins in ascending (i32, i32, i32) key order (:48-62).  Sorting the points by
+ * (key, index) and summing each run left to right performs the same additions in the same order.
+ * Returns the number of voxels; ox/oy/oz must hold n values.  voxel_size must be > 0 and finite
+ * (the reference asserts it, :13-16): returns (size_t)-1 otherwise. */
+size_t orc_voxel_downsample(const float *x, const float *y, const float *z, size_t n,
+                            float voxel_size, float *ox, float *oy, float *oz) {
+    if (!(voxel_size > 0.0f) || !isfinite(voxel_size)) return (size_t)-1;
+    if (n == 0) return 0;
+    voxel_entry *e = (voxel_entry *)malloc(n * sizeof(voxel_entry));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!finite3(x[i], y[i], z[i])) continue; /* :28-30 */
+        e[m].k[0] = sat_i32(floorf(x[i] / voxel_size)); /* :32-36 */
+        e[m].k[1] = sat_i32(floorf(y[i] / voxel_size));
+        e[m].k[2] = sat_i32(floorf(z[i] / voxel_size));
+        e[m].idx = (uint32_t)i;
+        ++m;
+    }
+    qsort(e, m, sizeof(voxel_entry), voxel_cmp);
+    size_t nv = 0;
+    for (size_t i = 0; i < m;) {
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        size_t cnt = 0, j = i;
+        while (j < m && e[j].k[0] == e[i].k[0] && e[j].k[1] == e[i].k[1] && e[j].k[2] == e[i].k[2]) {
+            sx += x[e[j].idx]; /* :38-41 */
+            sy += y[e[j].idx];
+            sz += z[e[j].idx];
+            ++cnt;
+            ++j;
+        }
+        float denom = (float)cnt; /* :57 */
+        ox[nv] = sx / denom;
+        oy[nv] = sy / denom;
+        oz[nv] = sz / denom;
+        ++nv;
+        i = j;
+    }
+    free(e);
+    return nv;
+}
+
+/* ------------------------------------------------------------------ */
 /* normals (estimate.rs:19-238)                                        */
 /* ------------------------------------------------------------------ */
 

@@ -511,6 +511,50 @@ int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const
     return PCRS_OK;
 }
 
+int pcrs_voxel_downsample_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                              size_t n, float voxel_size, float *dout_x, float *dout_y,
+                              float *dout_z, size_t *n_out) {
+    PCRS_TRY(bind_device(ctx));
+    if (!n_out) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    *n_out = 0;
+    if (!(voxel_size > 0.0f) || !std::isfinite(voxel_size))  // voxel_downsample.rs:13-16
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "voxel_size must be > 0 and finite");
+    if (n == 0) return PCRS_OK;
+    if (!dx || !dy || !dz || !dout_x || !dout_y || !dout_z)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    return pcrs_launch_voxel_downsample(ctx, dx, dy, dz, n, voxel_size, dout_x, dout_y, dout_z,
+                                        n_out);
+}
+
+int pcrs_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                          float voxel_size, float *out_x, float *out_y, float *out_z,
+                          size_t *n_out) {
+    PCRS_TRY(bind_device(ctx));
+    if (!n_out) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    *n_out = 0;
+    if (!(voxel_size > 0.0f) || !std::isfinite(voxel_size))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "voxel_size must be > 0 and finite");
+    if (n == 0) return PCRS_OK;
+    if (!x || !y || !z || !out_x || !out_y || !out_z)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    DevBuf d[3], o[3];
+    const float *src[3] = {x, y, z};
+    float *dst[3] = {out_x, out_y, out_z};
+    for (int a = 0; a < 3; ++a) {
+        PCRS_TRY(upload(ctx, d[a], src[a], n));
+        PCRS_HIP_CHECK(ctx, o[a].alloc(n * sizeof(float)));
+    }
+    size_t nv = 0;
+    PCRS_TRY(pcrs_launch_voxel_downsample(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(),
+                                          n, voxel_size, o[0].as<float>(), o[1].as<float>(),
+                                          o[2].as<float>(), &nv));
+    for (int a = 0; a < 3; ++a)
+        if (nv) PCRS_TRY(download(ctx, dst[a], o[a].p, nv * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = nv;
+    return PCRS_OK;
+}
+
 // -------------------------------------------------------------------------- SOR and normals
 
 static int check_range(pcrs_index *index, size_t q_begin, size_t q_count) {

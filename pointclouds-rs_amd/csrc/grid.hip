@@ -1365,6 +1365,26 @@ int pcrs_launch_radius_count_grid(pcrs_index *ix, const KnnQuery &q, float radiu
     return PCRS_OK;
 }
 
+// In-place exclusive scan of data[0..n) (u32); *total_out (device) receives the grand total.
+// sums must hold n / 1024 + 2 words.
+int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums,
+                         uint32_t *total_out) {
+    if (n == 0) {
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(total_out, 0, sizeof(uint32_t), ctx->stream));
+        return PCRS_OK;
+    }
+    if (n >= 0xFFFFFFFFull) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "scan too long");
+    const uint32_t nblocks = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream, data,
+                       (uint32_t)n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, nblocks,
+                       total_out);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream, data,
+                       (uint32_t)n, sums);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
 // ----------------------------------------------------------------------------- host: query
 
 int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in, uint32_t kneed) {

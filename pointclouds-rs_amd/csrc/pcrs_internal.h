@@ -187,6 +187,18 @@ int pcrs_launch_radius_count_grid(pcrs_index *ix, const KnnQuery &q, float radiu
 // keep[i] = count[i] >= min_neighbors (radius_outlier.rs:13)
 int pcrs_launch_count_mask(pcrs_ctx *ctx, const uint32_t *count, size_t n, size_t min_neighbors,
                            uint8_t *keep, unsigned long long *d_count);
+// In-place exclusive scan of data[0..n) (u32); *total_out (device) receives the grand total.
+// sums must hold n / 1024 + 2 words.
+int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums,
+                         uint32_t *total_out);
+// Stable LSD radix sort of (u64 key, u32 value) pairs on the low key_bits bits of the key
+// (sort.hip).  Both buffer pairs are used; *in_alt tells whether the result is in the alt pair.
+int pcrs_sort_pairs_u64(pcrs_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt,
+                        uint32_t *vals_alt, size_t n, int key_bits, bool *in_alt);
+// voxel_downsample on device columns (voxel.hip); ox/oy/oz hold up to n centroids.
+int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                                 size_t n, float voxel_size, float *ox, float *oy, float *oz,
+                                 size_t *n_out);
 // Writes the points in cell order (ties inside a cell by original index) as columns, with the
 // permutation sorted position -> original index.  Needs algo == GRID; all nvalid points.
 int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm);

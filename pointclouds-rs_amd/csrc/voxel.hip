@@ -1,0 +1,261 @@
+// voxel_downsample (crates/filters/src/voxel_downsample.rs:12-65) on the device:
+//   key      : (floor(p / voxel) as i32) per axis for every finite point        (:31-35)
+//   pack     : the three keys relative to their minima, packed so that one unsigned compare is
+//              the reference's lexicographic (i32, i32, i32) order               (:49-50)
+//   sort     : stable radix sort of (packed key, point index)
+//   centroid : one thread per voxel adds its points in ascending index order — the reference adds
+//              them in input order (:37-41) — and divides by the count          (:56-62)
+// Sums are f32 and sequential per voxel, so the centroids are bit-identical to the reference's.
+#include <climits>
+
+#include "knn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace pcrs {
+
+struct VoxelBounds {
+    int lo[3], hi[3];
+    unsigned int nvalid;
+    unsigned int pad;
+};
+
+// Rust `f32 as i32`: saturating, NaN -> 0 (not reached: non-finite points are skipped)
+__device__ __forceinline__ int sat_i32(float v) {
+    if (v >= 2147483648.0f) return INT_MAX;
+    if (v <= -2147483648.0f) return INT_MIN;
+    return (int)v;
+}
+
+__global__ __launch_bounds__(256) void voxel_key_kernel(const float *x, const float *y,
+                                                        const float *z, uint32_t n, float voxel,
+                                                        int *kx, int *ky, int *kz,
+                                                        VoxelBounds *bounds) {
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+    unsigned nv = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float px = x[i], py = y[i], pz = z[i];
+        int k[3] = {0, 0, 0};
+        if (finite3(px, py, pz)) {
+            k[0] = sat_i32(floorf(px / voxel));
+            k[1] = sat_i32(floorf(py / voxel));
+            k[2] = sat_i32(floorf(pz / voxel));
+            ++nv;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = min(lo[a], k[a]);
+                hi[a] = max(hi[a], k[a]);
+            }
+        }
+        kx[i] = k[0];
+        ky[i] = k[1];
+        kz[i] = k[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = min(lo[a], __shfl_down(lo[a], off, 64));
+            hi[a] = max(hi[a], __shfl_down(hi[a], off, 64));
+        }
+    for (int off = 32; off > 0; off >>= 1) nv += __shfl_down(nv, off, 64);
+    if ((threadIdx.x & 63) == 0 && nv) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bounds->lo[a], lo[a]);
+            atomicMax(&bounds->hi[a], hi[a]);
+        }
+        atomicAdd(&bounds->nvalid, nv);
+    }
+}
+
+// packed key of finite points; non-finite points get `invalid_key` (above every real key)
+__global__ __launch_bounds__(256) void voxel_pack_kernel(const float *x, const float *y,
+                                                         const float *z, uint32_t n, const int *kx,
+                                                         const int *ky, const int *kz, int lox,
+                                                         int loy, int loz, uint64_t ry,
+                                                         uint64_t rz, uint64_t invalid_key,
+                                                         uint64_t *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = invalid_key;
+    if (finite3(x[i], y[i], z[i])) {
+        const uint64_t dx = (uint64_t)((int64_t)kx[i] - (int64_t)lox);
+        const uint64_t dy = (uint64_t)((int64_t)ky[i] - (int64_t)loy);
+        const uint64_t dz = (uint64_t)((int64_t)kz[i] - (int64_t)loz);
+        key = (dx * ry + dy) * rz + dz;
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// head[i] = flag[i] = 1 where sorted position i starts a voxel (positions >= nvalid hold the
+// non-finite points).  Packed keys compare directly; the per-axis path compares the three keys of
+// neighbouring points.
+__global__ __launch_bounds__(256) void voxel_heads_kernel(const uint64_t *keys, uint32_t nvalid,
+                                                          uint32_t *head, uint8_t *flag) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvalid) return;
+    const uint32_t h = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    head[i] = h;
+    flag[i] = (uint8_t)h;
+}
+
+__global__ __launch_bounds__(256) void voxel_heads3_kernel(const uint32_t *order, uint32_t nvalid,
+                                                           const int *kx, const int *ky,
+                                                           const int *kz, uint32_t *head,
+                                                           uint8_t *flag) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvalid) return;
+    uint32_t h = 1u;
+    if (i != 0) {
+        const uint32_t p = order[i], q = order[i - 1];
+        h = (kx[p] != kx[q] || ky[p] != ky[q] || kz[p] != kz[q]) ? 1u : 0u;
+    }
+    head[i] = h;
+    flag[i] = (uint8_t)h;
+}
+
+// key of one axis for the current order (per-axis path); non-finite points sort last
+__global__ __launch_bounds__(256) void voxel_axis_key_kernel(const uint32_t *order, uint32_t n,
+                                                             const int *kaxis, int lo,
+                                                             uint64_t invalid_key, const float *x,
+                                                             const float *y, const float *z,
+                                                             uint64_t *keys) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = order[i];
+    keys[i] = finite3(x[p], y[p], z[p]) ? (uint64_t)((int64_t)kaxis[p] - (int64_t)lo) : invalid_key;
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *v, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+// One thread per voxel: adds its points in sorted (= ascending index) order.
+__global__ __launch_bounds__(256) void voxel_centroid_kernel(const uint8_t *flag,
+                                                             const uint32_t *order,
+                                                             const uint32_t *voxel_id,
+                                                             uint32_t nvalid, const float *x,
+                                                             const float *y, const float *z,
+                                                             float *ox, float *oy, float *oz) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvalid || !flag[i]) return;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    uint32_t cnt = 0;
+    uint32_t j = i;
+    do {
+        const uint32_t p = order[j];
+        sx += x[p];
+        sy += y[p];
+        sz += z[p];
+        ++cnt;
+        ++j;
+    } while (j < nvalid && !flag[j]);
+    const float denom = (float)cnt;  // a.n as f32
+    const uint32_t v = voxel_id[i];
+    ox[v] = sx / denom;
+    oy[v] = sy / denom;
+    oz[v] = sz / denom;
+}
+
+}  // namespace pcrs
+
+using namespace pcrs;
+
+int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                                 size_t n, float voxel_size, float *ox, float *oy, float *oz,
+                                 size_t *n_out) {
+    *n_out = 0;
+    if (n == 0) return PCRS_OK;
+    if (n >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    const uint32_t un = (uint32_t)n;
+    DevBuf k[3], dbounds, keys, vals, keys_alt, vals_alt, head, flag, sums;
+    for (int a = 0; a < 3; ++a) PCRS_HIP_CHECK(ctx, k[a].alloc(ctx, n * sizeof(int)));
+    PCRS_HIP_CHECK(ctx, dbounds.alloc(ctx, sizeof(VoxelBounds)));
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(VoxelBounds) + 64, &pin));
+    VoxelBounds *hb = reinterpret_cast<VoxelBounds *>(pin);
+    for (int a = 0; a < 3; ++a) {
+        hb->lo[a] = INT_MAX;
+        hb->hi[a] = INT_MIN;
+    }
+    hb->nvalid = 0;
+    hb->pad = 0;
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dbounds.p, hb, sizeof(VoxelBounds), hipMemcpyHostToDevice,
+                                       ctx->stream));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (size_t)ctx->num_cus * 8) blocks = (size_t)ctx->num_cus * 8;
+    hipLaunchKernelGGL(voxel_key_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, y, z,
+                       un, voxel_size, k[0].as<int>(), k[1].as<int>(), k[2].as<int>(),
+                       dbounds.as<VoxelBounds>());
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hb, dbounds.p, sizeof(VoxelBounds), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t nvalid = hb->nvalid;
+    if (nvalid == 0) return PCRS_OK;  // voxel_downsample.rs:44-46
+    const int lo[3] = {hb->lo[0], hb->lo[1], hb->lo[2]};
+    uint64_t range[3];
+    for (int a = 0; a < 3; ++a) range[a] = (uint64_t)((int64_t)hb->hi[a] - (int64_t)lo[a]) + 1u;
+    PCRS_HIP_CHECK(ctx, keys.alloc(ctx, n * sizeof(uint64_t)));
+    PCRS_HIP_CHECK(ctx, keys_alt.alloc(ctx, n * sizeof(uint64_t)));
+    PCRS_HIP_CHECK(ctx, vals.alloc(ctx, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, vals_alt.alloc(ctx, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, head.alloc(ctx, ((size_t)nvalid + 8) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, flag.alloc(ctx, (size_t)nvalid + 8));
+    PCRS_HIP_CHECK(ctx, sums.alloc(ctx, ((size_t)nvalid / 1024 + 4) * sizeof(uint32_t)));
+    const unsigned pblocks = (unsigned)((n + 255) / 256);
+    const unsigned vblocks = (nvalid + 255) / 256;
+    auto bits_for = [](uint64_t max_value) {
+        int b = 1;
+        while (b < 64 && (max_value >> b) != 0) ++b;
+        return b;
+    };
+    const uint32_t *order = nullptr;
+    const long double cells = (long double)range[0] * (long double)range[1] * (long double)range[2];
+    if (cells < 9.0e18L) {
+        // usual case: the three keys pack into one 63-bit key (one value above the largest key
+        // marks the non-finite points), one sort
+        const uint64_t invalid_key = range[0] * range[1] * range[2];
+        hipLaunchKernelGGL(voxel_pack_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, x, y, z, un,
+                           k[0].as<int>(), k[1].as<int>(), k[2].as<int>(), lo[0], lo[1], lo[2],
+                           range[1], range[2], invalid_key, keys.as<uint64_t>(),
+                           vals.as<uint32_t>());
+        bool in_alt = false;
+        PCRS_TRY(pcrs_sort_pairs_u64(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(),
+                                     keys_alt.as<uint64_t>(), vals_alt.as<uint32_t>(), n,
+                                     bits_for(invalid_key), &in_alt));
+        const uint64_t *skeys = in_alt ? keys_alt.as<uint64_t>() : keys.as<uint64_t>();
+        order = in_alt ? vals_alt.as<uint32_t>() : vals.as<uint32_t>();
+        hipLaunchKernelGGL(voxel_heads_kernel, dim3(vblocks), dim3(256), 0, ctx->stream, skeys,
+                           nvalid, head.as<uint32_t>(), flag.as<uint8_t>());
+    } else {
+        // keys spread over more than 2^63 cells (saturated coordinates): three stable sorts,
+        // least significant axis first
+        uint32_t *cur = vals.as<uint32_t>(), *alt = vals_alt.as<uint32_t>();
+        hipLaunchKernelGGL(iota_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, cur, un);
+        for (int a = 2; a >= 0; --a) {
+            hipLaunchKernelGGL(voxel_axis_key_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, cur,
+                               un, k[a].as<int>(), lo[a], range[a], x, y, z, keys.as<uint64_t>());
+            bool in_alt = false;
+            PCRS_TRY(pcrs_sort_pairs_u64(ctx, keys.as<uint64_t>(), cur, keys_alt.as<uint64_t>(),
+                                         alt, n, bits_for(range[a]), &in_alt));
+            if (in_alt) std::swap(cur, alt);
+        }
+        order = cur;
+        hipLaunchKernelGGL(voxel_heads3_kernel, dim3(vblocks), dim3(256), 0, ctx->stream, order,
+                           nvalid, k[0].as<int>(), k[1].as<int>(), k[2].as<int>(),
+                           head.as<uint32_t>(), flag.as<uint8_t>());
+    }
+    uint32_t *d_total = head.as<uint32_t>() + nvalid;
+    PCRS_TRY(pcrs_launch_scan_u32(ctx, head.as<uint32_t>(), nvalid, sums.as<uint32_t>(), d_total));
+    hipLaunchKernelGGL(voxel_centroid_kernel, dim3(vblocks), dim3(256), 0, ctx->stream,
+                       flag.as<uint8_t>(), order, head.as<uint32_t>(), nvalid, x, y, z, ox, oy, oz);
+    uint32_t *h_total = reinterpret_cast<uint32_t *>(pin);
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = *h_total;
+    return PCRS_OK;
+}

@@ -28,6 +28,7 @@ __all__ = [
     "IcpResult",
     "statistical_outlier_removal",
     "radius_outlier_removal",
+    "voxel_downsample",
     "estimate_normals",
     "icp_point_to_point",
     "icp_point_to_plane",
@@ -145,6 +146,18 @@ def statistical_outlier_removal(cloud, k, std_mul):
         raise ValueError("std_mul must be >= 0 and finite")
     keep, _, _, _ = hip.sor(cloud._x, cloud._y, cloud._z, int(k), std_mul)
     return cloud.select(np.nonzero(keep)[0])
+
+
+def voxel_downsample(cloud, voxel_size):
+    """crates/python/src/filters.rs:4-13 -> crates/filters/src/voxel_downsample.rs:12-65"""
+    _require_cloud(cloud)
+    voxel_size = float(voxel_size)
+    if not math.isfinite(voxel_size) or voxel_size <= 0.0:
+        raise ValueError("voxel_size must be > 0 and finite")
+    if cloud.is_empty():
+        return PointCloud()
+    x, y, z = hip.voxel_downsample(cloud._x, cloud._y, cloud._z, voxel_size)
+    return PointCloud._from_columns(x, y, z, None)
 
 
 def radius_outlier_removal(cloud, radius, min_neighbors):

@@ -63,6 +63,8 @@ SIGNATURES = {
     "pcrs_radius_count_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V]),
     "pcrs_radius_outlier": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, _V, _V,
                                                    c_size_p]),
+    "pcrs_voxel_downsample": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float] + _F3 + [c_size_p]),
+    "pcrs_voxel_downsample_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float] + _F3 + [c_size_p]),
     "pcrs_radius_outlier_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, _V, _V,
                                                        c_size_p]),
     "pcrs_sor_mean_dist_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, _V]),

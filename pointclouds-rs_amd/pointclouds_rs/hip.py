@@ -140,6 +140,20 @@ def radius_outlier(x, y, z, radius, min_neighbors, device=0):
     return keep.astype(bool), int(n_keep.value), count
 
 
+def voxel_downsample(x, y, z, voxel_size, device=0):
+    """voxel_downsample on columns: centroid columns (x, y, z) in voxel-key order."""
+    ctx = get_context(device)
+    x, y, z = _col(x), _col(y), _col(z)
+    n = len(x)
+    out = [np.empty(max(n, 1), dtype=np.float32) for _ in range(3)]
+    n_out = C.c_size_t(0)
+    ctx.check(
+        ctx.lib.pcrs_voxel_downsample(ctx.handle, _ptr(x), _ptr(y), _ptr(z), n, float(voxel_size),
+                                      *[_ptr(o) for o in out], C.byref(n_out))
+    )
+    return tuple(o[: n_out.value].copy() for o in out)
+
+
 def normals(x, y, z, k, viewpoint=(0.0, 0.0, 0.0), device=0):
     """estimate_normals_with_viewpoint on columns: (nx, ny, nz); empty when k == 0."""
     ctx = get_context(device)

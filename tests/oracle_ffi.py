@@ -115,6 +115,17 @@ class Oracle:
                                            _p(keep), _p(count))
         return keep.astype(bool), int(kept), count
 
+    def voxel_downsample(self, x, y, z, voxel_size):
+        x, y, z = map(_f, (x, y, z))
+        n = len(x)
+        out = [np.zeros(max(n, 1), dtype=np.float32) for _ in range(3)]
+        self.lib.orc_voxel_downsample.restype = C.c_size_t
+        self.lib.orc_voxel_downsample.argtypes = [_V, _V, _V, C.c_size_t, C.c_float, _V, _V, _V]
+        nv = self.lib.orc_voxel_downsample(_p(x), _p(y), _p(z), n, voxel_size, *[_p(o) for o in out])
+        if nv == C.c_size_t(-1).value:
+            raise ValueError("voxel_size must be > 0 and finite")
+        return tuple(o[:nv].copy() for o in out)
+
     def eigvec(self, a00, a01, a02, a11, a12, a22):
         out = (C.c_float * 3)()
         self.lib.orc_smallest_eigenvector_3x3(a00, a01, a02, a11, a12, a22, out)

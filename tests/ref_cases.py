@@ -47,6 +47,13 @@ class OracleImpl:
         keep, _, _, _ = self.o.sor(x, y, z, k, std_mul, self.algo)
         return keep
 
+    def voxel(self, x, y, z, size):
+        return self.o.voxel_downsample(x, y, z, size)
+
+    def radius_outlier(self, x, y, z, radius, min_neighbors):
+        keep, _, _ = self.o.radius_outlier(x, y, z, radius, min_neighbors)
+        return keep
+
     def normals(self, x, y, z, k, vp=(0, 0, 0)):
         return self.o.normals(x, y, z, k, vp, self.algo)
 
@@ -97,6 +104,13 @@ class HipImpl:
 
     def sor(self, x, y, z, k, std_mul):
         keep, _, _, _ = self.h.sor(x, y, z, k, std_mul)
+        return keep
+
+    def voxel(self, x, y, z, size):
+        return self.h.voxel_downsample(x, y, z, size)
+
+    def radius_outlier(self, x, y, z, radius, min_neighbors):
+        keep, _, _ = self.h.radius_outlier(x, y, z, radius, min_neighbors)
         return keep
 
     def normals(self, x, y, z, k, vp=(0, 0, 0)):
@@ -566,6 +580,53 @@ def case_plane_icp_converges_faster_than_point_to_point(impl):  # icp_plane.rs:4
     pl = impl.icp(1, src, tgt, n, max_iter=200, tol=1e-8)
     pt = impl.icp(0, src, tgt, max_iter=200, tol=1e-8)
     assert pl["num_iterations"] <= pt["num_iterations"] + 5
+
+
+# ------------------------------------------------------------------ voxel_downsample.rs
+
+
+def case_voxel_downsample_reduces_points(impl):  # voxel_downsample.rs:72-85
+    x, y, z = impl.voxel([0, 0.5, 0, 0.5, 0, 0.5, 0, 0.5], [0, 0, 0.5, 0.5, 0, 0, 0.5, 0.5],
+                         [0, 0, 0, 0, 0.5, 0.5, 0.5, 0.5], 1.0)
+    assert len(x) == 1
+    assert abs(x[0] - 0.25) < 1e-6 and abs(y[0] - 0.25) < 1e-6 and abs(z[0] - 0.25) < 1e-6
+
+
+def case_voxel_downsample_empty_cloud(impl):  # voxel_downsample.rs:88-91
+    x, y, z = impl.voxel([], [], [], 1.0)
+    assert len(x) == 0 and len(y) == 0 and len(z) == 0
+
+
+def case_voxel_downsample_single_point(impl):  # voxel_downsample.rs:94-99
+    x, y, z = impl.voxel([1.0], [2.0], [3.0], 1.0)
+    assert (len(x), x[0], y[0], z[0]) == (1, 1.0, 2.0, 3.0)
+
+
+def case_voxel_downsample_never_increases_points(impl):  # voxel_downsample.rs:102-116 (sampled)
+    rng = np.random.default_rng(5)
+    for _ in range(10):
+        n = int(rng.integers(1, 3000))
+        pts = rng.uniform(-100, 100, size=(n, 3)).astype(F)
+        size = float(rng.uniform(0.01, 10.0))
+        x, y, z = impl.voxel(pts[:, 0], pts[:, 1], pts[:, 2], size)
+        assert 1 <= len(x) <= n and len(x) == len(y) == len(z)
+
+
+# ------------------------------------------------------------------ radius_outlier.rs
+
+
+def case_radius_outlier_removes_isolated_points(impl):  # radius_outlier.rs:26-43
+    keep = impl.radius_outlier([0.0, 0.1, 0.2, 100.0], [0.0] * 4, [0.0] * 4, 0.5, 2)
+    assert list(keep) == [True, True, True, False]
+
+
+def case_radius_outlier_keeps_dense_cluster(impl):  # radius_outlier.rs:45-56
+    keep = impl.radius_outlier([0.0, 0.1, 0.2, 0.3, 0.4], [0.0] * 5, [0.0] * 5, 1.0, 2)
+    assert list(keep) == [True] * 5
+
+
+def case_radius_outlier_empty_cloud(impl):  # radius_outlier.rs:58-63
+    assert len(impl.radius_outlier([], [], [], 1.0, 2)) == 0
 
 
 # ------------------------------------------------------------------ tests/real_world_pipeline.rs

@@ -189,6 +189,28 @@ def test_radius_outlier_parity(hip, oracle, n):
     assert len(keep) == 0 and n_keep == 0
 
 
+def test_voxel_downsample_parity(hip, oracle):
+    """Centroids bit-identical to the CPU restatement: key order, per-voxel summation order,
+    negative coordinates, saturating keys, non-finite rows, one voxel holding everything."""
+    ux, uy, uz = gen.uniform_cloud(50000, 13, -40, 60)
+    dx, dy, dz = gen.degenerate_cloud(300, 5)
+    x, y, z = np.concatenate([ux, dx]), np.concatenate([uy, dy]), np.concatenate([uz, dz])
+    x = np.concatenate([x, np.array([3e9, -3e9, 1e20, 0.5], dtype=F)])
+    y = np.concatenate([y, np.array([1.0, 2.0, -1e20, 0.25], dtype=F)])
+    z = np.concatenate([z, np.array([0.0, 0.0, 7.0, -0.0], dtype=F)])
+    for size in (0.07, 0.5, 2.0, 33.3, 1e6):
+        got = hip.voxel_downsample(x, y, z, size)
+        ref = oracle.voxel_downsample(x, y, z, size)
+        assert len(got[0]) == len(ref[0]), size
+        for a, b in zip(got, ref):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), size
+    nan = np.full(5, np.nan, dtype=F)
+    assert len(hip.voxel_downsample(nan, nan, nan, 1.0)[0]) == 0
+    for bad in (0.0, -1.0, float("nan"), float("inf")):
+        with pytest.raises(Exception):
+            hip.voxel_downsample(x, y, z, bad)
+
+
 def test_apply_transform_bit_exact(hip, oracle):
     x, y, z = gen.uniform_cloud(10000, 4, -50, 50)
     R = gen.rot_z(0.3)

@@ -122,3 +122,30 @@ def test_p2p_recovers_rigid_motion(oracle):
     rc, res, _ = oracle.icp(0, (x, y, z), (tx, ty, tz), max_iter=30, tol=1e-9)
     assert rc == 0 and res.rmse < 1e-4
     assert np.allclose(np.array(res.rot).reshape(3, 3), R, atol=1e-4)
+
+
+def test_voxel_downsample_against_dict_restatement(oracle):
+    """Second, independent restatement of voxel_downsample.rs:24-62 (a dict of running f32 sums in
+    input order, keys sorted at the end) against the sort-based oracle."""
+    rng = np.random.default_rng(17)
+    for n, size in ((1, 1.0), (500, 0.8), (3000, 3.3), (2000, 0.05)):
+        pts = rng.uniform(-30, 30, size=(n, 3)).astype(np.float32)
+        pts[rng.integers(0, n, size=max(n // 50, 1))] = np.nan
+        f = np.float32
+        bins = {}
+        for px, py, pz in pts:
+            if not (np.isfinite(px) and np.isfinite(py) and np.isfinite(pz)):
+                continue
+            key = tuple(int(np.floor(f(v) / f(size))) for v in (px, py, pz))
+            a = bins.setdefault(key, [f(0), f(0), f(0), 0])
+            a[0] = f(a[0] + px)
+            a[1] = f(a[1] + py)
+            a[2] = f(a[2] + pz)
+            a[3] += 1
+        keys = sorted(bins)
+        ref = np.array([[f(bins[k][i] / f(bins[k][3])) for i in range(3)] for k in keys],
+                       dtype=np.float32).reshape(-1, 3)
+        got = oracle.voxel_downsample(pts[:, 0], pts[:, 1], pts[:, 2], size)
+        assert len(got[0]) == len(keys)
+        for i in range(3):
+            assert np.array_equal(got[i].view(np.uint32), ref[:, i].copy().view(np.uint32))

@@ -147,6 +147,27 @@ int pcrs_voxel_downsample_dev(pcrs_ctx *ctx, const float *dx, const float *dy, c
                               size_t n, float voxel_size, float *dout_x, float *dout_y,
                               float *dout_z, size_t *n_out);
 
+/* ransac_plane_seeded behind its sample generation —
+ * crates/segmentation/src/ransac_plane.rs:56-138.  The reference draws n_samples index
+ * triples from rand's StdRng (:75-79, sample_three_distinct :141-165) and the caller
+ * passes exactly those (samples[3*s .. 3*s+2], the triples that sampling returned, in
+ * order).  The library fits one plane per triple (:168-191), counts the inliers of
+ * every plane over the cloud (|n.p + d| <= distance_threshold, :17-20,131-137), picks
+ * the plane the reference picks — earliest plane with the largest count when
+ * n >= 10000 and n_samples >= 16 (:81-94), otherwise the sequential scan with its
+ * adaptive early stop (:96-122) — and returns model = {nx, ny, nz, d} and the inlier
+ * mask of that plane (:125-128; the caller turns it into ascending indices).
+ * n < 3, or no usable triple, gives the default plane (0,0,1,0) (:64-66, :23-30).
+ * best_count (nullable) receives the winning inlier count. */
+int pcrs_ransac_plane_samples(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                              size_t n, const uint32_t *samples, size_t n_samples,
+                              float distance_threshold, float model[4], uint8_t *inlier_mask,
+                              size_t *n_inliers, uint64_t *best_count);
+int pcrs_ransac_plane_samples_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                                  size_t n, const uint32_t *dsamples, size_t n_samples,
+                                  float distance_threshold, float model[4], uint8_t *dinlier_mask,
+                                  size_t *n_inliers, uint64_t *best_count);
+
 /* ------------------------------------------- statistical_outlier_removal */
 
 /* The per-point loop of statistical_outlier_removal —

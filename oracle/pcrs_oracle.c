@@ -566,6 +566,86 @@ size_t orc_voxel_downsample(const float *x, const float *y, const float *z, size
 }
 
 /* ------------------------------------------------------------------ */
+/* ransac_plane_seeded behind its sample generation                    */
+/* (crates/segmentation/src/ransac_plane.rs:56-138)                    */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    float n[3], d;
+} plane_model;
+
+/* :168-191 */
+static int fit_plane3(const float p0[3], const float p1[3], const float p2[3], plane_model *m) {
+    float v1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    float v2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    float nx = v1[1] * v2[2] - v1[2] * v2[1];
+    float ny = v1[2] * v2[0] - v1[0] * v2[2];
+    float nz = v1[0] * v2[1] - v1[1] * v2[0];
+    float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    if (len < 1e-10f) return 0;
+    m->n[0] = nx / len;
+    m->n[1] = ny / len;
+    m->n[2] = nz / len;
+    m->d = -(m->n[0] * p0[0] + m->n[1] * p0[1] + m->n[2] * p0[2]);
+    return 1;
+}
+
+/* :17-20 */
+static float plane_distance(const plane_model *m, float x, float y, float z) {
+    return fabsf(m->n[0] * x + m->n[1] * y + m->n[2] * z + m->d);
+}
+
+/* `samples` holds the ns index triples that the reference's sampling (:75-79) produced, in order.
+ * model_out = {nx, ny, nz, d}; mask[n] = inliers of the chosen plane; returns their number. */
+size_t orc_ransac_plane_samples(const float *x, const float *y, const float *z, size_t n,
+                                const uint32_t *samples, size_t ns, float thr, float model_out[4],
+                                unsigned char *mask, uint64_t *best_count_out) {
+    plane_model best = {{0.0f, 0.0f, 1.0f}, 0.0f}; /* :23-30 */
+    size_t best_count = 0;
+    model_out[0] = 0.0f, model_out[1] = 0.0f, model_out[2] = 1.0f, model_out[3] = 0.0f;
+    if (best_count_out) *best_count_out = 0;
+    if (n < 3) { /* :64-66 */
+        for (size_t i = 0; i < n; ++i) mask[i] = 0;
+        return 0;
+    }
+    int use_parallel = n >= 10000 && ns >= 16; /* :81 */
+    int have = 0;
+    for (size_t s = 0; s < ns; ++s) {
+        uint32_t i0 = samples[3 * s], i1 = samples[3 * s + 1], i2 = samples[3 * s + 2];
+        float p0[3] = {x[i0], y[i0], z[i0]}, p1[3] = {x[i1], y[i1], z[i1]},
+              p2[3] = {x[i2], y[i2], z[i2]};
+        plane_model m;
+        if (!fit_plane3(p0, p1, p2, &m)) continue;
+        size_t c = 0; /* :131-137 */
+        for (size_t j = 0; j < n; ++j) c += plane_distance(&m, x[j], y[j], z[j]) <= thr;
+        if (use_parallel) { /* :83-94: the earliest plane with the largest count */
+            if (!have || c > best_count) {
+                best = m;
+                best_count = c;
+                have = 1;
+            }
+        } else if (c > best_count) { /* :106-120 */
+            best_count = c;
+            best = m;
+            double w = (double)best_count / (double)n;
+            if (w > 0.5) {
+                double needed = log(1.0 - 0.999) / log(1.0 - w * w * w);
+                if ((double)s > needed) break;
+            }
+        }
+    }
+    size_t kept = 0; /* :125-128 */
+    for (size_t j = 0; j < n; ++j) {
+        mask[j] = (unsigned char)(plane_distance(&best, x[j], y[j], z[j]) <= thr);
+        kept += mask[j];
+    }
+    model_out[0] = best.n[0], model_out[1] = best.n[1], model_out[2] = best.n[2];
+    model_out[3] = best.d;
+    if (best_count_out) *best_count_out = best_count;
+    return kept;
+}
+
+/* ------------------------------------------------------------------ */
 /* normals (estimate.rs:19-238)                                        */
 /* ------------------------------------------------------------------ */
 

@@ -555,6 +555,44 @@ int pcrs_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const f
     return PCRS_OK;
 }
 
+int pcrs_ransac_plane_samples_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                                  size_t n, const uint32_t *dsamples, size_t n_samples,
+                                  float distance_threshold, float model[4], uint8_t *dinlier_mask,
+                                  size_t *n_inliers, uint64_t *best_count) {
+    PCRS_TRY(bind_device(ctx));
+    if (!model || !n_inliers) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    if (n && (!dx || !dy || !dz || !dinlier_mask))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    if (n_samples && !dsamples) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null samples");
+    return pcrs_launch_ransac_plane(ctx, dx, dy, dz, n, dsamples, n_samples, distance_threshold,
+                                    model, dinlier_mask, n_inliers, best_count);
+}
+
+int pcrs_ransac_plane_samples(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                              size_t n, const uint32_t *samples, size_t n_samples,
+                              float distance_threshold, float model[4], uint8_t *inlier_mask,
+                              size_t *n_inliers, uint64_t *best_count) {
+    PCRS_TRY(bind_device(ctx));
+    if (!model || !n_inliers) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    if (n && (!x || !y || !z || !inlier_mask))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    if (n_samples && !samples) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null samples");
+    DevBuf d[3], dmask, dsamp;
+    const float *src[3] = {x, y, z};
+    for (int a = 0; a < 3; ++a) PCRS_TRY(upload(ctx, d[a], src[a], n));
+    PCRS_HIP_CHECK(ctx, dmask.alloc(n));
+    PCRS_HIP_CHECK(ctx, dsamp.alloc(3 * n_samples * sizeof(uint32_t)));
+    if (n_samples)
+        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dsamp.p, samples, 3 * n_samples * sizeof(uint32_t),
+                                           hipMemcpyHostToDevice, ctx->stream));
+    PCRS_TRY(pcrs_launch_ransac_plane(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(), n,
+                                      dsamp.as<uint32_t>(), n_samples, distance_threshold, model,
+                                      dmask.as<uint8_t>(), n_inliers, best_count));
+    if (n) PCRS_TRY(download(ctx, inlier_mask, dmask.p, n));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCRS_OK;
+}
+
 // -------------------------------------------------------------------------- SOR and normals
 
 static int check_range(pcrs_index *index, size_t q_begin, size_t q_count) {

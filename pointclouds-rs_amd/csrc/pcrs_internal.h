@@ -199,6 +199,12 @@ int pcrs_sort_pairs_u64(pcrs_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t 
 int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                                  size_t n, float voxel_size, float *ox, float *oy, float *oz,
                                  size_t *n_out);
+// Plane RANSAC behind its sample generation (ransac.hip): d_samples holds ns index triples,
+// d_mask receives the inlier mask of the chosen plane.
+int pcrs_launch_ransac_plane(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                             size_t n, const uint32_t *d_samples, size_t ns, float thr,
+                             float model_out[4], uint8_t *d_mask, size_t *n_inliers,
+                             uint64_t *best_count_out);
 // Writes the points in cell order (ties inside a cell by original index) as columns, with the
 // permutation sorted position -> original index.  Needs algo == GRID; all nvalid points.
 int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm);

@@ -29,6 +29,9 @@ __all__ = [
     "statistical_outlier_removal",
     "radius_outlier_removal",
     "voxel_downsample",
+    "ransac_plane",
+    "ransac_plane_seeded",
+    "PlaneResult",
     "estimate_normals",
     "icp_point_to_point",
     "icp_point_to_plane",
@@ -158,6 +161,75 @@ def voxel_downsample(cloud, voxel_size):
         return PointCloud()
     x, y, z = hip.voxel_downsample(cloud._x, cloud._y, cloud._z, voxel_size)
     return PointCloud._from_columns(x, y, z, None)
+
+
+class PlaneResult:
+    """crates/python/src/segmentation.rs:19-41"""
+
+    def __init__(self, normal, d, inliers):
+        self.normal = [float(v) for v in normal]
+        self.d = float(d)
+        self.inliers = [int(i) for i in inliers]
+
+    def __repr__(self):
+        return "PlaneResult(normal=%r, d=%.4f, inliers=%d)" % (self.normal, self.d, len(self.inliers))
+
+
+def sample_triples(n, iterations, seed):
+    """The sampling procedure of ransac_plane.rs:141-165 (three distinct indices, up to 100 retries
+    each) over a SplitMix64 stream.  The reference draws from rand's StdRng (ChaCha12), which
+    cannot be reproduced without that crate: a Rust caller passes its own triples to
+    pcrs_ransac_plane_samples, this generator only serves the Python mirror."""
+    if n < 3:
+        return np.zeros((0, 3), dtype=np.uint32)
+    mask = (1 << 64) - 1
+    state = [int(seed) & mask]
+
+    def below(m):
+        state[0] = (state[0] + 0x9E3779B97F4A7C15) & mask
+        v = state[0]
+        v = ((v ^ (v >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        v = ((v ^ (v >> 27)) * 0x94D049BB133111EB) & mask
+        v ^= v >> 31
+        return (v * m) >> 64
+
+    out = []
+    for _ in range(int(iterations)):
+        i0 = below(n)
+        i1 = below(n)
+        attempts = 0
+        while i1 == i0 and attempts <= 100:
+            i1 = below(n)
+            attempts += 1
+        if i1 == i0:
+            continue
+        i2 = below(n)
+        attempts = 0
+        while (i2 == i0 or i2 == i1) and attempts <= 100:
+            i2 = below(n)
+            attempts += 1
+        if i2 == i0 or i2 == i1:
+            continue
+        out.append((i0, i1, i2))
+    return np.array(out, dtype=np.uint32).reshape(-1, 3)
+
+
+def ransac_plane_seeded(cloud, distance_threshold, iterations, seed):
+    """crates/segmentation/src/ransac_plane.rs:56-138 with the mirror's own sample stream."""
+    _require_cloud(cloud)
+    if iterations < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    samples = sample_triples(cloud.len(), iterations, seed)
+    normal, d, inliers, _ = hip.ransac_plane_samples(cloud._x, cloud._y, cloud._z, samples,
+                                                     float(distance_threshold))
+    return PlaneResult(normal, d, inliers)
+
+
+def ransac_plane(cloud, distance_threshold, iterations):
+    """crates/python/src/segmentation.rs:43-57: random seed (ransac_plane.rs:36-43)."""
+    import secrets
+
+    return ransac_plane_seeded(cloud, distance_threshold, iterations, secrets.randbits(64))
 
 
 def radius_outlier_removal(cloud, radius, min_neighbors):

@@ -154,6 +154,27 @@ def voxel_downsample(x, y, z, voxel_size, device=0):
     return tuple(o[: n_out.value].copy() for o in out)
 
 
+def ransac_plane_samples(x, y, z, samples, distance_threshold, device=0):
+    """ransac_plane_seeded behind its sample generation: samples is an (S, 3) index array.
+    Returns (normal[3], d, inlier indices ascending, best inlier count)."""
+    ctx = get_context(device)
+    x, y, z = _col(x), _col(y), _col(z)
+    n = len(x)
+    smp = np.ascontiguousarray(np.asarray(samples, dtype=np.uint32).reshape(-1, 3))
+    model = (C.c_float * 4)()
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    n_in = C.c_size_t(0)
+    best = C.c_uint64(0)
+    ctx.check(
+        ctx.lib.pcrs_ransac_plane_samples(ctx.handle, _ptr(x), _ptr(y), _ptr(z), n, _ptr(smp),
+                                          len(smp), float(distance_threshold), model, _ptr(mask),
+                                          C.byref(n_in), C.byref(best))
+    )
+    inliers = np.nonzero(mask[:n])[0]
+    assert len(inliers) == n_in.value
+    return np.array(model[:3], dtype=np.float32), float(model[3]), inliers, int(best.value)
+
+
 def normals(x, y, z, k, viewpoint=(0.0, 0.0, 0.0), device=0):
     """estimate_normals_with_viewpoint on columns: (nx, ny, nz); empty when k == 0."""
     ctx = get_context(device)

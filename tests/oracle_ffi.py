@@ -126,6 +126,22 @@ class Oracle:
             raise ValueError("voxel_size must be > 0 and finite")
         return tuple(o[:nv].copy() for o in out)
 
+    def ransac_plane_samples(self, x, y, z, samples, thr):
+        x, y, z = map(_f, (x, y, z))
+        n = len(x)
+        smp = np.ascontiguousarray(np.asarray(samples, dtype=np.uint32).reshape(-1, 3))
+        model = (C.c_float * 4)()
+        mask = np.zeros(max(n, 1), dtype=np.uint8)
+        best = C.c_uint64(0)
+        self.lib.orc_ransac_plane_samples.restype = C.c_size_t
+        self.lib.orc_ransac_plane_samples.argtypes = [_V, _V, _V, C.c_size_t, _V, C.c_size_t,
+                                                      C.c_float, _V, _V, _V]
+        kept = self.lib.orc_ransac_plane_samples(_p(x), _p(y), _p(z), n, _p(smp), len(smp), thr,
+                                                 model, _p(mask), C.byref(best))
+        inl = np.nonzero(mask[:n])[0]
+        assert len(inl) == kept
+        return np.array(model[:3], dtype=np.float32), float(model[3]), inl, int(best.value)
+
     def eigvec(self, a00, a01, a02, a11, a12, a22):
         out = (C.c_float * 3)()
         self.lib.orc_smallest_eigenvector_3x3(a00, a01, a02, a11, a12, a22, out)

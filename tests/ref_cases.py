@@ -54,6 +54,11 @@ class OracleImpl:
         keep, _, _ = self.o.radius_outlier(x, y, z, radius, min_neighbors)
         return keep
 
+    def ransac(self, x, y, z, thr, iterations, seed):
+        from pointclouds_rs import sample_triples
+
+        return self.o.ransac_plane_samples(x, y, z, sample_triples(len(x), iterations, seed), thr)[:3]
+
     def normals(self, x, y, z, k, vp=(0, 0, 0)):
         return self.o.normals(x, y, z, k, vp, self.algo)
 
@@ -112,6 +117,11 @@ class HipImpl:
     def radius_outlier(self, x, y, z, radius, min_neighbors):
         keep, _, _ = self.h.radius_outlier(x, y, z, radius, min_neighbors)
         return keep
+
+    def ransac(self, x, y, z, thr, iterations, seed):
+        from pointclouds_rs import sample_triples
+
+        return self.h.ransac_plane_samples(x, y, z, sample_triples(len(x), iterations, seed), thr)[:3]
 
     def normals(self, x, y, z, k, vp=(0, 0, 0)):
         return self.h.normals(x, y, z, k, vp)
@@ -627,6 +637,61 @@ def case_radius_outlier_keeps_dense_cluster(impl):  # radius_outlier.rs:45-56
 
 def case_radius_outlier_empty_cloud(impl):  # radius_outlier.rs:58-63
     assert len(impl.radius_outlier([], [], [], 1.0, 2)) == 0
+
+
+# ------------------------------------------------------------------ ransac_plane.rs
+# The reference seeds rand's StdRng; these cases run the same clouds with the mirror's own sample
+# stream (the asserted properties do not depend on which triples are drawn).
+
+
+def _grid(nx, ny, sx, sy, zf):
+    x = [i * sx for i in range(nx) for j in range(ny)]
+    y = [j * sy for i in range(nx) for j in range(ny)]
+    z = [zf(a, b) for a, b in zip(x, y)]
+    return np.array(x, F), np.array(y, F), np.array(z, F)
+
+
+def case_ransac_fit_xy_plane(impl):  # ransac_plane.rs:200-224
+    x, y, z = _grid(20, 20, F(0.1), F(0.1), lambda a, b: 0.0)
+    nrm, d, inl = impl.ransac(x, y, z, 0.01, 100, 42)
+    assert abs(nrm[2]) > 0.99 and abs(d) < 0.01 and len(inl) == 400
+
+
+def case_ransac_fit_offset_plane(impl):  # ransac_plane.rs:227-255
+    x, y, z = _grid(10, 10, 1.0, 1.0, lambda a, b: 5.0)
+    nrm, d, inl = impl.ransac(x, y, z, 0.01, 100, 42)
+    assert abs(nrm[2]) > 0.99 and abs(abs(d) - 5.0) < 0.01 and len(inl) == 100
+
+
+def case_ransac_fit_tilted_plane(impl):  # ransac_plane.rs:258-308
+    x, y, z = _grid(10, 10, F(0.1), F(0.1), lambda a, b: F(1.0) - F(a) - F(b))
+    nrm, d, inl = impl.ransac(x, y, z, 0.01, 100, 42)
+    e = 1.0 / math.sqrt(3.0)
+    assert all(abs(abs(float(c)) - e) < 0.05 for c in nrm) and len(inl) == 100
+
+
+def case_ransac_plane_with_outliers(impl):  # ransac_plane.rs:311-356
+    x, y, z = _grid(7, 7, 1.0, 1.0, lambda a, b: 0.0)
+    x = np.concatenate([x, np.arange(10, dtype=F)])
+    y = np.concatenate([y, np.arange(10, dtype=F)])
+    z = np.concatenate([z, np.full(10, 100.0, F)])
+    nrm, d, inl = impl.ransac(x, y, z, 0.1, 200, 42)
+    assert abs(nrm[2]) > 0.9 and len(inl) >= 49 and all(abs(z[i]) < 1.0 for i in inl)
+
+
+def case_ransac_empty_and_tiny_clouds(impl):  # ransac_plane.rs:359-380
+    for pts in (([], [], []), ([0.0, 1.0], [0.0, 0.0], [0.0, 0.0]), ([0.0], [0.0], [0.0])):
+        nrm, d, inl = impl.ransac(*pts, 0.1, 100, 42)
+        assert list(nrm) == [0.0, 0.0, 1.0] and d == 0.0 and len(inl) == 0
+
+
+def case_ransac_seeded_is_deterministic(impl):  # ransac_plane.rs:407-421
+    x = [0.0, 1.0, 2.0, 3.0, 4.0] * 2
+    y = [0.0] * 5 + [1.0] * 5
+    z = [0.0] * 10
+    a = impl.ransac(x, y, z, 0.01, 50, 123)
+    b = impl.ransac(x, y, z, 0.01, 50, 123)
+    assert list(a[0]) == list(b[0]) and a[1] == b[1] and list(a[2]) == list(b[2])
 
 
 # ------------------------------------------------------------------ tests/real_world_pipeline.rs

@@ -211,6 +211,33 @@ def test_voxel_downsample_parity(hip, oracle):
             hip.voxel_downsample(x, y, z, bad)
 
 
+@pytest.mark.parametrize("n,ns", [(3000, 200), (60000, 400), (60000, 8)],
+                         ids=["sequential", "parallel", "few-samples"])
+def test_ransac_plane_parity(hip, oracle, n, ns):
+    """Same triples in, same plane / inliers / count out: both selection rules of the reference
+    (early-stopping scan below 10000 points or 16 samples, earliest maximum above)."""
+    import pointclouds_rs as pc
+
+    rng = np.random.default_rng(n + ns)
+    xy = rng.uniform(-20, 20, size=(n, 2)).astype(F)
+    zc = (0.02 * xy[:, 0] - 0.01 * xy[:, 1] + 1.5 + rng.normal(0, 0.01, n)).astype(F)
+    out = rng.random(n) < 0.3
+    zc[out] = rng.uniform(-10, 10, int(out.sum())).astype(F)
+    x, y, z = xy[:, 0].copy(), xy[:, 1].copy(), zc
+    x[5], z[9] = np.nan, np.inf
+    samples = pc.sample_triples(n, ns, 7)
+    samples[3] = (1, 1, 2)  # coincident points: no plane
+    for thr in (0.03, 0.5, 0.0):
+        got = hip.ransac_plane_samples(x, y, z, samples, thr)
+        ref = oracle.ransac_plane_samples(x, y, z, samples, thr)
+        assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), thr
+        assert np.float32(got[1]).view(np.uint32) == np.float32(ref[1]).view(np.uint32)
+        assert np.array_equal(got[2], ref[2]) and got[3] == ref[3]
+    none = hip.ransac_plane_samples(x, y, z, np.zeros((0, 3), np.uint32), 0.1)
+    rnone = oracle.ransac_plane_samples(x, y, z, np.zeros((0, 3), np.uint32), 0.1)
+    assert list(none[0]) == [0.0, 0.0, 1.0] and none[1] == 0.0 and np.array_equal(none[2], rnone[2])
+
+
 def test_apply_transform_bit_exact(hip, oracle):
     x, y, z = gen.uniform_cloud(10000, 4, -50, 50)
     R = gen.rot_z(0.3)

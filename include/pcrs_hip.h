@@ -147,6 +147,22 @@ int pcrs_voxel_downsample_dev(pcrs_ctx *ctx, const float *dx, const float *dy, c
                               size_t n, float voxel_size, float *dout_x, float *dout_y,
                               float *dout_z, size_t *n_out);
 
+/* euclidean_cluster — crates/segmentation/src/euclidean_cluster.rs:96-187: connected
+ * components of "distance <= distance_threshold" (pairs are examined, as in the
+ * reference, when their cells floor(p / threshold) are equal or adjacent), clusters
+ * with min_size <= size <= max_size only, largest first, ties by smallest index,
+ * indices ascending inside a cluster; non-finite points are clusters of one.  The
+ * result is in CSR form: cluster c holds indices[offsets[c] .. offsets[c+1]).
+ * offsets must hold n + 1 entries, indices n.  An empty cloud, a threshold <= 0 or
+ * min_size == 0 gives no clusters (:102-104). */
+int pcrs_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                           float distance_threshold, size_t min_size, size_t max_size,
+                           uint32_t *offsets, uint32_t *indices, size_t *n_clusters);
+int pcrs_euclidean_cluster_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                               size_t n, float distance_threshold, size_t min_size,
+                               size_t max_size, uint32_t *doffsets, uint32_t *dindices,
+                               size_t *n_clusters, size_t *n_indices);
+
 /* ransac_plane_seeded behind its sample generation —
  * crates/segmentation/src/ransac_plane.rs:56-138.  The reference draws n_samples index
  * triples from rand's StdRng (:75-79, sample_three_distinct :141-165) and the caller

@@ -646,6 +646,153 @@ size_t orc_ransac_plane_samples(const float *x, const float *y, const float *z, 
 }
 
 /* ------------------------------------------------------------------ */
+/* euclidean_cluster (crates/segmentation/src/euclidean_cluster.rs)    */
+/* ------------------------------------------------------------------ */
+
+static uint32_t uf_find(uint32_t *parent, uint32_t x) { /* :21-29 */
+    while (parent[x] != x) {
+        uint32_t p = parent[x];
+        parent[x] = parent[p];
+        x = parent[x];
+    }
+    return x;
+}
+
+typedef struct {
+    uint32_t label, idx;
+} label_entry;
+
+static int label_cmp(const void *pa, const void *pb) {
+    const label_entry *a = (const label_entry *)pa, *b = (const label_entry *)pb;
+    if (a->label != b->label) return a->label < b->label ? -1 : 1;
+    return (a->idx > b->idx) - (a->idx < b->idx);
+}
+
+typedef struct {
+    uint32_t start, size;
+} cluster_entry;
+
+static int cluster_cmp(const void *pa, const void *pb) { /* :184: size desc, then smallest index */
+    const cluster_entry *a = (const cluster_entry *)pa, *b = (const cluster_entry *)pb;
+    if (a->size != b->size) return a->size > b->size ? -1 : 1;
+    return (a->start > b->start) - (a->start < b->start);
+}
+
+static int64_t key_rank(const voxel_entry *cells, size_t nc, int64_t kx, int64_t ky, int64_t kz) {
+    size_t lo = 0, hi = nc;
+    while (lo < hi) {
+        size_t mid = lo + (hi - lo) / 2;
+        const int32_t *k = cells[mid].k;
+        int less = k[0] < kx || (k[0] == kx && (k[1] < ky || (k[1] == ky && k[2] < kz)));
+        if (less)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < nc && cells[lo].k[0] == kx && cells[lo].k[1] == ky && cells[lo].k[2] == kz)
+        return (int64_t)lo;
+    return -1;
+}
+
+/* Connected components of the graph "distance <= threshold" restricted, as in the reference, to
+ * pairs whose cells floor(p / threshold) are equal or adjacent (:107-160); non-finite points are
+ * singletons (:111-113, :171-175).  Output in CSR form: offsets[nc + 1], indices; clusters by
+ * size descending then smallest index, indices ascending (:177-186).  Returns the cluster count.
+ * The order of the unions (:163-168) does not change the components. */
+size_t orc_euclidean_cluster(const float *x, const float *y, const float *z, size_t n, float thr,
+                             size_t min_size, size_t max_size, uint32_t *offsets,
+                             uint32_t *indices) {
+    offsets[0] = 0;
+    if (n == 0 || thr <= 0.0f || min_size == 0) return 0; /* :102-104 */
+    float inv_r = 1.0f / thr, r2 = thr * thr;          /* :107-108 */
+    voxel_entry *e = (voxel_entry *)malloc(n * sizeof(voxel_entry));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!finite3(x[i], y[i], z[i])) continue;
+        e[m].k[0] = sat_i32(floorf(x[i] * inv_r)); /* :56-62 */
+        e[m].k[1] = sat_i32(floorf(y[i] * inv_r));
+        e[m].k[2] = sat_i32(floorf(z[i] * inv_r));
+        e[m].idx = (uint32_t)i;
+        ++m;
+    }
+    qsort(e, m, sizeof(voxel_entry), voxel_cmp);
+    /* unique cells: key + first position */
+    voxel_entry *cells = (voxel_entry *)malloc((m + 1) * sizeof(voxel_entry));
+    size_t nc = 0;
+    for (size_t i = 0; i < m; ++i)
+        if (i == 0 || e[i].k[0] != e[i - 1].k[0] || e[i].k[1] != e[i - 1].k[1] ||
+            e[i].k[2] != e[i - 1].k[2]) {
+            cells[nc] = e[i];
+            cells[nc].idx = (uint32_t)i;
+            ++nc;
+        }
+    cells[nc].idx = (uint32_t)m;
+    uint32_t *parent = (uint32_t *)malloc(n * sizeof(uint32_t));
+    for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+    static const int off[14][3] = {{0, 0, 0},  {1, 0, 0},  {1, 1, 0},   {1, -1, 0}, {1, 0, 1},
+                                   {1, 0, -1}, {1, 1, 1},  {1, 1, -1},  {1, -1, 1}, {1, -1, -1},
+                                   {0, 1, 0},  {0, 1, 1},  {0, 1, -1},  {0, 0, 1}}; /* :66-83 */
+    for (size_t c = 0; c < nc; ++c) {
+        for (int o = 0; o < 14; ++o) {
+            int64_t b = key_rank(cells, nc, (int64_t)cells[c].k[0] + off[o][0],
+                                 (int64_t)cells[c].k[1] + off[o][1],
+                                 (int64_t)cells[c].k[2] + off[o][2]);
+            if (b < 0) continue;
+            for (size_t ai = cells[c].idx; ai < cells[c + 1].idx; ++ai) {
+                uint32_t ia = e[ai].idx;
+                size_t start = (o == 0) ? ai + 1 : cells[b].idx; /* :148 */
+                for (size_t bi = start; bi < cells[b + 1].idx; ++bi) {
+                    uint32_t ib = e[bi].idx;
+                    float dx = x[ia] - x[ib], dy = y[ia] - y[ib], dz = z[ia] - z[ib];
+                    if (dx * dx + dy * dy + dz * dz <= r2) { /* :151-153 */
+                        uint32_t ra = uf_find(parent, ia), rb = uf_find(parent, ib);
+                        if (ra != rb) {
+                            if (ra < rb)
+                                parent[rb] = ra;
+                            else
+                                parent[ra] = rb;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    label_entry *lab = (label_entry *)malloc(n * sizeof(label_entry));
+    for (size_t i = 0; i < n; ++i) {
+        lab[i].label = uf_find(parent, (uint32_t)i);
+        lab[i].idx = (uint32_t)i;
+    }
+    qsort(lab, n, sizeof(label_entry), label_cmp);
+    cluster_entry *cl = (cluster_entry *)malloc(n * sizeof(cluster_entry));
+    size_t ncl = 0;
+    for (size_t i = 0; i < n;) {
+        size_t j = i;
+        while (j < n && lab[j].label == lab[i].label) ++j;
+        size_t size = j - i;
+        if (size >= min_size && size <= max_size) { /* :179 */
+            cl[ncl].start = (uint32_t)i;
+            cl[ncl].size = (uint32_t)size;
+            ++ncl;
+        }
+        i = j;
+    }
+    /* positions in `lab` are ordered by label = smallest index, so `start` breaks ties as :184 */
+    qsort(cl, ncl, sizeof(cluster_entry), cluster_cmp);
+    size_t w = 0;
+    for (size_t c = 0; c < ncl; ++c) {
+        offsets[c] = (uint32_t)w;
+        for (uint32_t t = 0; t < cl[c].size; ++t) indices[w++] = lab[cl[c].start + t].idx;
+    }
+    offsets[ncl] = (uint32_t)w;
+    free(cl);
+    free(lab);
+    free(parent);
+    free(cells);
+    free(e);
+    return ncl;
+}
+
+/* ------------------------------------------------------------------ */
 /* normals (estimate.rs:19-238)                                        */
 /* ------------------------------------------------------------------ */
 

@@ -593,6 +593,52 @@ int pcrs_ransac_plane_samples(pcrs_ctx *ctx, const float *x, const float *y, con
     return PCRS_OK;
 }
 
+int pcrs_euclidean_cluster_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                               size_t n, float distance_threshold, size_t min_size,
+                               size_t max_size, uint32_t *doffsets, uint32_t *dindices,
+                               size_t *n_clusters, size_t *n_indices) {
+    PCRS_TRY(bind_device(ctx));
+    if (!n_clusters) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    *n_clusters = 0;
+    size_t ni = 0;
+    if (n_indices) *n_indices = 0;
+    if (n == 0) return PCRS_OK;
+    if (!dx || !dy || !dz || !doffsets || !dindices)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    PCRS_TRY(pcrs_launch_euclidean_cluster(ctx, dx, dy, dz, n, distance_threshold, min_size,
+                                           max_size, doffsets, dindices, n_clusters, &ni));
+    if (n_indices) *n_indices = ni;
+    return PCRS_OK;
+}
+
+int pcrs_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                           float distance_threshold, size_t min_size, size_t max_size,
+                           uint32_t *offsets, uint32_t *indices, size_t *n_clusters) {
+    PCRS_TRY(bind_device(ctx));
+    if (!n_clusters || !offsets) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    *n_clusters = 0;
+    offsets[0] = 0;
+    if (n == 0) return PCRS_OK;
+    if (!x || !y || !z || !indices)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    DevBuf d[3], doff, didx;
+    const float *src[3] = {x, y, z};
+    for (int a = 0; a < 3; ++a) PCRS_TRY(upload(ctx, d[a], src[a], n));
+    PCRS_HIP_CHECK(ctx, doff.alloc((n + 1) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, didx.alloc(n * sizeof(uint32_t)));
+    size_t nc = 0, ni = 0;
+    PCRS_TRY(pcrs_launch_euclidean_cluster(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(),
+                                           n, distance_threshold, min_size, max_size,
+                                           doff.as<uint32_t>(), didx.as<uint32_t>(), &nc, &ni));
+    if (nc) {
+        PCRS_TRY(download(ctx, offsets, doff.p, (nc + 1) * sizeof(uint32_t)));
+        if (ni) PCRS_TRY(download(ctx, indices, didx.p, ni * sizeof(uint32_t)));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *n_clusters = nc;
+    return PCRS_OK;
+}
+
 // -------------------------------------------------------------------------- SOR and normals
 
 static int check_range(pcrs_index *index, size_t q_begin, size_t q_count) {

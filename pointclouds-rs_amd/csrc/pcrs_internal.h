@@ -195,6 +195,20 @@ int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums
 // (sort.hip).  Both buffer pairs are used; *in_alt tells whether the result is in the alt pair.
 int pcrs_sort_pairs_u64(pcrs_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt,
                         uint32_t *vals_alt, size_t n, int key_bits, bool *in_alt);
+// Points ordered by an integer cell key per axis (voxel.hip): key = floor(p / scale) or
+// floor(p * scale) as a saturating i32, finite points only, cells in ascending (x, y, z) key
+// order, points of a cell in ascending index order.
+struct PcrsCellSort {
+    DevBuf k[3];                  // int [n]: the three keys of every point (0 for non-finite)
+    DevBuf keys, keys_alt, vals, vals_alt;  // sort buffers; `order` points into vals or vals_alt
+    DevBuf cell_id;               // u32 [nvalid + 1]: exclusive scan of the cell-start flags
+    DevBuf flag;                  // u8 [nvalid]: 1 where a sorted position starts a cell
+    const uint32_t *order = nullptr;  // [nvalid] point index at each sorted position
+    const uint32_t *d_ncells = nullptr;  // device: number of occupied cells
+    uint32_t nvalid = 0;          // finite points
+};
+int pcrs_cell_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                   float scale, bool multiply, PcrsCellSort *cs);
 // voxel_downsample on device columns (voxel.hip); ox/oy/oz hold up to n centroids.
 int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                                  size_t n, float voxel_size, float *ox, float *oy, float *oz,
@@ -205,6 +219,12 @@ int pcrs_launch_ransac_plane(pcrs_ctx *ctx, const float *x, const float *y, cons
                              size_t n, const uint32_t *d_samples, size_t ns, float thr,
                              float model_out[4], uint8_t *d_mask, size_t *n_inliers,
                              uint64_t *best_count_out);
+// euclidean_cluster on device columns (cluster.hip): CSR output, d_offsets holds up to n + 1
+// entries and d_indices up to n.
+int pcrs_launch_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                                  size_t n, float threshold, size_t min_size, size_t max_size,
+                                  uint32_t *d_offsets, uint32_t *d_indices, size_t *n_clusters,
+                                  size_t *n_indices);
 // Writes the points in cell order (ties inside a cell by original index) as columns, with the
 // permutation sorted position -> original index.  Needs algo == GRID; all nvalid points.
 int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm);

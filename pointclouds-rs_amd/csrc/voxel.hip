@@ -20,16 +20,19 @@ struct VoxelBounds {
     unsigned int pad;
 };
 
-// Rust `f32 as i32`: saturating, NaN -> 0 (not reached: non-finite points are skipped)
+// Rust `f32 as i32`: saturating, NaN -> 0
 __device__ __forceinline__ int sat_i32(float v) {
+    if (v != v) return 0;
     if (v >= 2147483648.0f) return INT_MAX;
     if (v <= -2147483648.0f) return INT_MIN;
     return (int)v;
 }
 
+// multiply == false: floor(p / scale)  (voxel_downsample.rs:31-35)
+// multiply == true : floor(p * scale)  (euclidean_cluster.rs:56-62, scale = 1 / threshold)
 __global__ __launch_bounds__(256) void voxel_key_kernel(const float *x, const float *y,
-                                                        const float *z, uint32_t n, float voxel,
-                                                        int *kx, int *ky, int *kz,
+                                                        const float *z, uint32_t n, float scale,
+                                                        bool multiply, int *kx, int *ky, int *kz,
                                                         VoxelBounds *bounds) {
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
     unsigned nv = 0;
@@ -37,9 +40,9 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const float *x, const fl
         const float px = x[i], py = y[i], pz = z[i];
         int k[3] = {0, 0, 0};
         if (finite3(px, py, pz)) {
-            k[0] = sat_i32(floorf(px / voxel));
-            k[1] = sat_i32(floorf(py / voxel));
-            k[2] = sat_i32(floorf(pz / voxel));
+            k[0] = sat_i32(floorf(multiply ? px * scale : px / scale));
+            k[1] = sat_i32(floorf(multiply ? py * scale : py / scale));
+            k[2] = sat_i32(floorf(multiply ? pz * scale : pz / scale));
             ++nv;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -163,16 +166,16 @@ __global__ __launch_bounds__(256) void voxel_centroid_kernel(const uint8_t *flag
 
 using namespace pcrs;
 
-int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
-                                 size_t n, float voxel_size, float *ox, float *oy, float *oz,
-                                 size_t *n_out) {
-    *n_out = 0;
+int pcrs_cell_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                   float scale, bool multiply, PcrsCellSort *cs) {
+    cs->nvalid = 0;
+    cs->order = nullptr;
     if (n == 0) return PCRS_OK;
     if (n >= 0xFFFFFFFFull)
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
     const uint32_t un = (uint32_t)n;
-    DevBuf k[3], dbounds, keys, vals, keys_alt, vals_alt, head, flag, sums;
-    for (int a = 0; a < 3; ++a) PCRS_HIP_CHECK(ctx, k[a].alloc(ctx, n * sizeof(int)));
+    DevBuf dbounds;
+    for (int a = 0; a < 3; ++a) PCRS_HIP_CHECK(ctx, cs->k[a].alloc(ctx, n * sizeof(int)));
     PCRS_HIP_CHECK(ctx, dbounds.alloc(ctx, sizeof(VoxelBounds)));
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(VoxelBounds) + 64, &pin));
@@ -188,16 +191,20 @@ int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, 
     size_t blocks = (n + 255) / 256;
     if (blocks > (size_t)ctx->num_cus * 8) blocks = (size_t)ctx->num_cus * 8;
     hipLaunchKernelGGL(voxel_key_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, y, z,
-                       un, voxel_size, k[0].as<int>(), k[1].as<int>(), k[2].as<int>(),
-                       dbounds.as<VoxelBounds>());
+                       un, scale, multiply, cs->k[0].as<int>(), cs->k[1].as<int>(),
+                       cs->k[2].as<int>(), dbounds.as<VoxelBounds>());
     PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hb, dbounds.p, sizeof(VoxelBounds), hipMemcpyDeviceToHost,
                                        ctx->stream));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t nvalid = hb->nvalid;
-    if (nvalid == 0) return PCRS_OK;  // voxel_downsample.rs:44-46
+    cs->nvalid = nvalid;
+    if (nvalid == 0) return PCRS_OK;
     const int lo[3] = {hb->lo[0], hb->lo[1], hb->lo[2]};
     uint64_t range[3];
     for (int a = 0; a < 3; ++a) range[a] = (uint64_t)((int64_t)hb->hi[a] - (int64_t)lo[a]) + 1u;
+    DevBuf &keys = cs->keys, &keys_alt = cs->keys_alt, &vals = cs->vals, &vals_alt = cs->vals_alt;
+    DevBuf &head = cs->cell_id, &flag = cs->flag;
+    DevBuf sums;
     PCRS_HIP_CHECK(ctx, keys.alloc(ctx, n * sizeof(uint64_t)));
     PCRS_HIP_CHECK(ctx, keys_alt.alloc(ctx, n * sizeof(uint64_t)));
     PCRS_HIP_CHECK(ctx, vals.alloc(ctx, n * sizeof(uint32_t)));
@@ -219,8 +226,8 @@ int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, 
         // marks the non-finite points), one sort
         const uint64_t invalid_key = range[0] * range[1] * range[2];
         hipLaunchKernelGGL(voxel_pack_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, x, y, z, un,
-                           k[0].as<int>(), k[1].as<int>(), k[2].as<int>(), lo[0], lo[1], lo[2],
-                           range[1], range[2], invalid_key, keys.as<uint64_t>(),
+                           cs->k[0].as<int>(), cs->k[1].as<int>(), cs->k[2].as<int>(), lo[0], lo[1],
+                           lo[2], range[1], range[2], invalid_key, keys.as<uint64_t>(),
                            vals.as<uint32_t>());
         bool in_alt = false;
         PCRS_TRY(pcrs_sort_pairs_u64(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(),
@@ -237,7 +244,8 @@ int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, 
         hipLaunchKernelGGL(iota_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, cur, un);
         for (int a = 2; a >= 0; --a) {
             hipLaunchKernelGGL(voxel_axis_key_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, cur,
-                               un, k[a].as<int>(), lo[a], range[a], x, y, z, keys.as<uint64_t>());
+                               un, cs->k[a].as<int>(), lo[a], range[a], x, y, z,
+                               keys.as<uint64_t>());
             bool in_alt = false;
             PCRS_TRY(pcrs_sort_pairs_u64(ctx, keys.as<uint64_t>(), cur, keys_alt.as<uint64_t>(),
                                          alt, n, bits_for(range[a]), &in_alt));
@@ -245,16 +253,34 @@ int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, 
         }
         order = cur;
         hipLaunchKernelGGL(voxel_heads3_kernel, dim3(vblocks), dim3(256), 0, ctx->stream, order,
-                           nvalid, k[0].as<int>(), k[1].as<int>(), k[2].as<int>(),
+                           nvalid, cs->k[0].as<int>(), cs->k[1].as<int>(), cs->k[2].as<int>(),
                            head.as<uint32_t>(), flag.as<uint8_t>());
     }
-    uint32_t *d_total = head.as<uint32_t>() + nvalid;
-    PCRS_TRY(pcrs_launch_scan_u32(ctx, head.as<uint32_t>(), nvalid, sums.as<uint32_t>(), d_total));
-    hipLaunchKernelGGL(voxel_centroid_kernel, dim3(vblocks), dim3(256), 0, ctx->stream,
-                       flag.as<uint8_t>(), order, head.as<uint32_t>(), nvalid, x, y, z, ox, oy, oz);
+    cs->order = order;
+    cs->d_ncells = head.as<uint32_t>() + nvalid;
+    PCRS_TRY(pcrs_launch_scan_u32(ctx, head.as<uint32_t>(), nvalid, sums.as<uint32_t>(),
+                                  head.as<uint32_t>() + nvalid));
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                                 size_t n, float voxel_size, float *ox, float *oy, float *oz,
+                                 size_t *n_out) {
+    *n_out = 0;
+    if (n == 0) return PCRS_OK;
+    PcrsCellSort cs;
+    PCRS_TRY(pcrs_cell_sort(ctx, x, y, z, n, voxel_size, false, &cs));
+    if (cs.nvalid == 0) return PCRS_OK;  // voxel_downsample.rs:44-46
+    const uint32_t nvalid = cs.nvalid;
+    hipLaunchKernelGGL(voxel_centroid_kernel, dim3((nvalid + 255) / 256), dim3(256), 0, ctx->stream,
+                       cs.flag.as<uint8_t>(), cs.order, cs.cell_id.as<uint32_t>(), nvalid, x, y, z,
+                       ox, oy, oz);
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &pin));
     uint32_t *h_total = reinterpret_cast<uint32_t *>(pin);
-    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                       ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_total, cs.d_ncells, sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = *h_total;
     return PCRS_OK;

@@ -30,6 +30,7 @@ __all__ = [
     "radius_outlier_removal",
     "voxel_downsample",
     "ransac_plane",
+    "euclidean_cluster",
     "ransac_plane_seeded",
     "PlaneResult",
     "estimate_normals",
@@ -161,6 +162,17 @@ def voxel_downsample(cloud, voxel_size):
         return PointCloud()
     x, y, z = hip.voxel_downsample(cloud._x, cloud._y, cloud._z, voxel_size)
     return PointCloud._from_columns(x, y, z, None)
+
+
+def euclidean_cluster(cloud, distance_threshold, min_size, max_size):
+    """crates/python/src/segmentation.rs:4-17 -> euclidean_cluster.rs:96-187: list of index lists."""
+    _require_cloud(cloud)
+    if min_size < 0 or max_size < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    max_size = min(int(max_size), (1 << 64) - 1)
+    out = hip.euclidean_cluster(cloud._x, cloud._y, cloud._z, float(distance_threshold),
+                                int(min_size), max_size)
+    return [[int(i) for i in c] for c in out]
 
 
 class PlaneResult:

@@ -69,6 +69,10 @@ SIGNATURES = {
                                                          _V, c_size_p, _V]),
     "pcrs_ransac_plane_samples_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, _V, C.c_size_t, C.c_float,
                                                              _V, _V, c_size_p, _V]),
+    "pcrs_euclidean_cluster": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, C.c_size_t,
+                                                      _V, _V, c_size_p]),
+    "pcrs_euclidean_cluster_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t,
+                                                          C.c_size_t, _V, _V, c_size_p, c_size_p]),
     "pcrs_radius_outlier_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, _V, _V,
                                                        c_size_p]),
     "pcrs_sor_mean_dist_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, _V]),

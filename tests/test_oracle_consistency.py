@@ -149,3 +149,26 @@ def test_voxel_downsample_against_dict_restatement(oracle):
         assert len(got[0]) == len(keys)
         for i in range(3):
             assert np.array_equal(got[i].view(np.uint32), ref[:, i].copy().view(np.uint32))
+
+
+def test_euclidean_cluster_against_dense_graph(oracle):
+    """The cell-restricted restatement against connected components of the dense
+    "distance <= threshold" graph (scipy), same f32 distance expression."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    rng = np.random.default_rng(23)
+    f = np.float32
+    for n, thr in ((300, 1.5), (800, 0.9), (500, 4.0)):
+        p = rng.uniform(-10, 10, size=(n, 3)).astype(f)
+        d = p[:, None, :] - p[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        adj = csr_matrix(d2 <= f(thr) * f(thr))
+        ncomp, lab = connected_components(adj, directed=False)
+        comps = [np.nonzero(lab == c)[0] for c in range(ncomp)]
+        comps = [c for c in comps if 2 <= len(c) <= 200]
+        comps.sort(key=lambda c: (-len(c), c[0]))
+        got = oracle.euclidean_cluster(p[:, 0], p[:, 1], p[:, 2], thr, 2, 200)
+        assert len(got) == len(comps)
+        for a, b in zip(got, comps):
+            assert np.array_equal(a, b)

@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=POINTS_PER_GPU, help="points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true",
+                    help="skip the side timings of the stages around the hot path")
     ap.add_argument("--icp-iters", type=int, default=50, help="ICP iterations for the side metric (0 = skip)")
     args = ap.parse_args()
 
@@ -134,6 +136,9 @@ def main():
     icp_line = None
     if args.icp_iters > 0 and rank == 0:
         icp_line = bench_icp(engine, synth, args.icp_iters)
+    stages_line = None
+    if not args.no_stages and rank == 0 and world == 1:
+        stages_line = bench_stages(engine, shard, args.points)
 
     if rank == 0:
         out = {
@@ -174,11 +179,89 @@ def main():
         }
         if icp_line:
             out["icp"] = icp_line
+        if stages_line:
+            out["other_stages"] = stages_line
+        out["roofline"]["traffic"] = pmc_traffic()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(*full_host)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the neighbour-search kernel from the committed counter passes
+    (profiles/, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this benchmark);
+    None when the summary is not there.  FETCH_SIZE and WRITE_SIZE are in KiB; the kernel reads
+    16-byte points per lane from scattered slots, an access pattern for which the counter is not
+    calibrated, so the figure is reported as read."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    for name, counters in d.items():
+        if "knn_cell_kernel<17, true>" in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            return (counters["FETCH_SIZE"]["mean_per_launch"] + counters["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+    return None
+
+
+def bench_stages(engine, cols, n):
+    """Side timings (not the headline metric) of the stages either side of the hot path on the
+    same resident cloud: voxel_downsample, radius_outlier_removal, plane RANSAC behind its
+    sampling, euclidean_cluster.  Wall time of the device-pointer entry points, median of 5."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    lib, ctx = engine.lib, engine.ctx
+    p = engine._p
+    out = {}
+
+    def timed(fn, reps=5):
+        ts = []
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts[1:]))
+
+    ox, oy, oz = (engine.empty(n) for _ in range(3))
+    nv = C.c_size_t(0)
+    dt = timed(lambda: ctx.check(lib.pcrs_voxel_downsample_dev(ctx.handle, *[p(c) for c in cols], n, 1.0,
+                                                              p(ox), p(oy), p(oz), C.byref(nv))))
+    out["voxel_downsample"] = {"voxel_size": 1.0, "voxels": int(nv.value), "ms": dt * 1e3,
+                               "Mpoints_per_s": n / dt / 1e6}
+    keep = engine.empty(n, "uint8")
+    nk = C.c_size_t(0)
+    dt = timed(lambda: ctx.check(lib.pcrs_radius_outlier_dev(ctx.handle, *[p(c) for c in cols], n, 1.5, 12,
+                                                            p(keep), None, C.byref(nk))))
+    out["radius_outlier_removal"] = {"radius": 1.5, "min_neighbors": 12, "kept": int(nk.value),
+                                     "ms": dt * 1e3, "Mpoints_per_s": n / dt / 1e6}
+    from pointclouds_rs import sample_triples
+
+    smp = engine.torch.from_numpy(sample_triples(n, 1000, 1).astype(np.int64).astype(np.int32)).to(engine.device)
+    model = (C.c_float * 4)()
+    nin = C.c_size_t(0)
+    best = C.c_uint64(0)
+    ns = smp.shape[0]
+    dt = timed(lambda: ctx.check(lib.pcrs_ransac_plane_samples_dev(
+        ctx.handle, *[p(c) for c in cols], n, p(smp), ns, 0.5, model, p(keep), C.byref(nin), C.byref(best))))
+    out["ransac_plane"] = {"samples": int(ns), "threshold": 0.5, "inliers": int(nin.value), "ms": dt * 1e3,
+                           "Gpoint_plane_tests_per_s": n * ns / dt / 1e9}
+    offs = engine.empty(n + 1, "int32")
+    idx = engine.empty(n, "int32")
+    nc = C.c_size_t(0)
+    ni = C.c_size_t(0)
+    dt = timed(lambda: ctx.check(lib.pcrs_euclidean_cluster_dev(
+        ctx.handle, *[p(c) for c in cols], n, 0.8, 2, n, p(offs), p(idx), C.byref(nc), C.byref(ni))))
+    out["euclidean_cluster"] = {"threshold": 0.8, "min_size": 2, "clusters": int(nc.value),
+                                "ms": dt * 1e3, "Mpoints_per_s": n / dt / 1e6}
+    return out
 
 
 def bench_icp(engine, synth, iters):

@@ -435,8 +435,9 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
         float D[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
+        const pcrs_f2 qxy = {qx, qy};
         walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t) {
-            const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+            const float d2 = sqdist_pk(qxy, qz, p);
 #pragma unroll
             for (int s = K - 1; s > 0; --s) D[s] = __builtin_amdgcn_fmed3f(d2, D[s - 1], D[s]);
             D[0] = fminf(D[0], d2);
@@ -503,7 +504,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
             uint32_t hits = 0;
             walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t s) {
-                const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+                const float d2 = sqdist_pk(qxy, qz, p);
                 if (d2 <= tau) {
                     if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = s;
                     ++hits;
@@ -1080,7 +1081,7 @@ double target_occupancy(uint32_t k_hint) {
         const double v = atof(e);
         if (v >= 0.5 && v <= 256.0) return v;
     }
-    double p = 0.5 * (double)(k_hint ? k_hint : 16);
+    double p = 0.42 * (double)(k_hint ? k_hint : 16);
     if (p < 2.0) p = 2.0;
     if (p > 64.0) p = 64.0;
     return p;

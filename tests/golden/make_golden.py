@@ -66,6 +66,49 @@ def main():
     path = os.path.join(HERE, "oracle_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+    stage_vectors(o)
+
+
+def flat_clusters(cl):
+    """list of index arrays -> (offsets, indices)"""
+    off = np.cumsum([0] + [len(c) for c in cl]).astype(np.uint32)
+    idx = np.concatenate(cl).astype(np.uint32) if cl else np.zeros(0, np.uint32)
+    return off, idx
+
+
+def stage_vectors(o):
+    """tests/golden/stage_vectors.npz: the stages next to the KNN path (radius outlier, voxel
+    downsample, plane RANSAC behind its sampling, Euclidean clustering) on three small clouds."""
+    from pointclouds_rs import sample_triples
+
+    out = {}
+    cl = {
+        "uniform3000": synth.uniform_cloud(3000, 5, 0, 20),
+        "degenerate300": synth.degenerate_cloud(300, 7),
+        "kitti4000": synth.kitti_scene(4000, 42),
+    }
+    for name, (x, y, z) in cl.items():
+        out[f"{name}/xyz"] = np.stack([x, y, z])
+        for r, mn in ((0.5, 2), (1.5, 5)):
+            keep, _, count = o.radius_outlier(x, y, z, r, mn)
+            out[f"{name}/radius{r}_{mn}/keep"] = keep
+            out[f"{name}/radius{r}_{mn}/count"] = count
+        for size in (0.3, 2.0):
+            out[f"{name}/voxel{size}"] = np.stack(o.voxel_downsample(x, y, z, size))
+        smp = sample_triples(len(x), 64, 11)
+        out[f"{name}/ransac/samples"] = smp
+        for thr in (0.05, 0.5):
+            nrm, d, inl, best = o.ransac_plane_samples(x, y, z, smp, thr)
+            out[f"{name}/ransac{thr}/model"] = np.array([*nrm, d], dtype=np.float32)
+            out[f"{name}/ransac{thr}/inliers"] = inl.astype(np.uint32)
+            out[f"{name}/ransac{thr}/best"] = np.uint64(best)
+        for thr, mn, mx in ((0.4, 1, 10 ** 6), (1.0, 3, 500)):
+            off, idx = flat_clusters(o.euclidean_cluster(x, y, z, thr, mn, mx))
+            out[f"{name}/cluster{thr}_{mn}_{mx}/offsets"] = off
+            out[f"{name}/cluster{thr}_{mn}_{mx}/indices"] = idx
+    path = os.path.join(HERE, "stage_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -85,7 +85,7 @@ def stage_vectors(o):
     cl = {
         "uniform3000": synth.uniform_cloud(3000, 5, 0, 20),
         "degenerate300": synth.degenerate_cloud(300, 7),
-        "kitti4000": synth.kitti_scene(4000, 42),
+        "kitti3700": synth.kitti_scene(42, 2000, 500, 200),
     }
     for name, (x, y, z) in cl.items():
         out[f"{name}/xyz"] = np.stack([x, y, z])

@@ -263,6 +263,37 @@ def test_euclidean_cluster_parity(hip, oracle):
     assert hip.euclidean_cluster(x, y, z, 1.0, 0, 10) == []
 
 
+def test_obstacle_pipeline_matches_oracle(hip, oracle):
+    """The reference's obstacle-detection pipeline (examples/python/kitti_obstacle_detection.py:87-124:
+    voxel 0.15 -> SOR k=20 x2.0 -> RANSAC ground 0.15 / 500 -> drop ground -> clusters 0.8 / 10 /
+    20000) stage by stage against the CPU restatement, each stage fed with the previous stage's
+    GPU output."""
+    import pointclouds_rs as pc
+
+    x, y, z = gen.kitti_scene(43, 40000, 2500, 800)
+    g = hip.voxel_downsample(x, y, z, 0.15)
+    r = oracle.voxel_downsample(x, y, z, 0.15)
+    for a, b in zip(g, r):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    keep, n_keep, thr, _ = hip.sor(*g, 20, 2.0)
+    rkeep, rn, rthr, _ = oracle.sor(*g, 20, 2.0, algo=1)
+    assert np.array_equal(keep, rkeep) and n_keep == rn and np.float32(thr) == np.float32(rthr)
+    c = [col[keep] for col in g]
+    smp = pc.sample_triples(len(c[0]), 500, 1234)
+    nrm, d, inl, best = hip.ransac_plane_samples(*c, smp, 0.15)
+    rnrm, rd, rinl, rbest = oracle.ransac_plane_samples(*c, smp, 0.15)
+    assert np.array_equal(nrm.view(np.uint32), rnrm.view(np.uint32)) and d == rd and best == rbest
+    assert np.array_equal(inl, rinl) and abs(nrm[2]) > 0.95 and len(inl) > 0.5 * len(c[0])
+    mask = np.ones(len(c[0]), dtype=bool)
+    mask[inl] = False
+    obst = [col[mask] for col in c]
+    cl = hip.euclidean_cluster(*obst, 0.8, 10, 20000)
+    rcl = oracle.euclidean_cluster(*obst, 0.8, 10, 20000)
+    assert len(cl) == len(rcl) >= 3
+    for a, b in zip(cl, rcl):
+        assert np.array_equal(a, b)
+
+
 def test_apply_transform_bit_exact(hip, oracle):
     x, y, z = gen.uniform_cloud(10000, 4, -50, 50)
     R = gen.rot_z(0.3)

@@ -348,7 +348,8 @@ struct CellArgs {
     uint32_t kcollect;      // neighbours whose identity is needed (pass 2), 0 = none
 };
 
-// Calls f(point, slot) for every point of the (2R+1)^3 cube of cells centred on (cx, cy, cz).
+// Calls f(point, address of the point in the sorted array) for every point of the (2R+1)^3 cube
+// of cells centred on (cx, cy, cz).
 template <class F>
 __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int cz, F f) {
     const GridGeom &g = a.g;
@@ -363,19 +364,21 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
             const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
             const uint32_t s0 = a.cell_start[row + x0];
             const uint32_t s1 = a.cell_start[row + x1 + 1];
-            // four loads in flight per iteration: the walk is latency-bound, not VALU-bound
-            uint32_t s = s0;
-            for (; s + 3 < s1; s += 4) {
-                const float4 p0 = a.spts[s];
-                const float4 p1 = a.spts[s + 1];
-                const float4 p2 = a.spts[s + 2];
-                const float4 p3 = a.spts[s + 3];
-                f(p0, s);
-                f(p1, s + 1);
-                f(p2, s + 2);
-                f(p3, s + 3);
+            // four loads in flight per iteration, addressed off one running pointer so that
+            // the loads use immediate offsets instead of four 64-bit address computations
+            const float4 *pp = a.spts + s0;
+            const float4 *const pe = a.spts + s1;
+            for (; pp + 3 < pe; pp += 4) {
+                const float4 p0 = pp[0];
+                const float4 p1 = pp[1];
+                const float4 p2 = pp[2];
+                const float4 p3 = pp[3];
+                f(p0, pp);
+                f(p1, pp + 1);
+                f(p2, pp + 2);
+                f(p3, pp + 3);
             }
-            for (; s < s1; ++s) f(a.spts[s], s);
+            for (; pp < pe; ++pp) f(*pp, pp);
         }
     }
 }
@@ -436,7 +439,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 #pragma unroll
         for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
         const pcrs_f2 qxy = {qx, qy};
-        walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t) {
+        walk_cube(a, cx, cy, cz, [&](const float4 &p, const float4 *) {
             const float d2 = sqdist_pk(qxy, qz, p);
 #pragma unroll
             for (int s = K - 1; s > 0; --s) D[s] = __builtin_amdgcn_fmed3f(d2, D[s - 1], D[s]);
@@ -503,10 +506,10 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             for (int i = 0; i < K; ++i)
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
             uint32_t hits = 0;
-            walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t s) {
+            walk_cube(a, cx, cy, cz, [&](const float4 &p, const float4 *at) {
                 const float d2 = sqdist_pk(qxy, qz, p);
                 if (d2 <= tau) {
-                    if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = s;
+                    if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = (uint32_t)(at - a.spts);
                     ++hits;
                 }
             });
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(GB_THREADS) void radius_cell_kernel(CellArgs a, flo
             const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
             const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
             const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
-            walk_cube(a, cx, cy, cz, [&](const float4 &p, uint32_t) {
+            walk_cube(a, cx, cy, cz, [&](const float4 &p, const float4 *) {
                 c += (sqdist(qx, qy, qz, p.x, p.y, p.z) <= r2) ? 1u : 0u;
             });
         }

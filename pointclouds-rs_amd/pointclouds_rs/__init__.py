@@ -31,6 +31,9 @@ __all__ = [
     "voxel_downsample",
     "ransac_plane",
     "euclidean_cluster",
+    "read_pcd",
+    "write_pcd",
+    "write_pcd_binary",
     "ransac_plane_seeded",
     "PlaneResult",
     "estimate_normals",
@@ -162,6 +165,33 @@ def voxel_downsample(cloud, voxel_size):
         return PointCloud()
     x, y, z = hip.voxel_downsample(cloud._x, cloud._y, cloud._z, voxel_size)
     return PointCloud._from_columns(x, y, z, None)
+
+
+def read_pcd(path):
+    """crates/python/src/io.rs:4-9 -> crates/io/src/pcd.rs:7-21; IOError on a bad file."""
+    from . import io as _io
+
+    try:
+        x, y, z = _io.read_pcd_columns(path)
+    except ValueError as e:
+        raise IOError(str(e))
+    return PointCloud._from_columns(x, y, z, None)
+
+
+def write_pcd(path, cloud):
+    """crates/python/src/io.rs:11-15 -> crates/io/src/pcd.rs:24-43 (ASCII)."""
+    from . import io as _io
+
+    _require_cloud(cloud)
+    _io.write_pcd_columns(path, cloud._x, cloud._y, cloud._z)
+
+
+def write_pcd_binary(path, cloud):
+    """crates/io/src/pcd.rs:46-71."""
+    from . import io as _io
+
+    _require_cloud(cloud)
+    _io.write_pcd_binary_columns(path, cloud._x, cloud._y, cloud._z)
 
 
 def euclidean_cluster(cloud, distance_threshold, min_size, max_size):

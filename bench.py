@@ -105,10 +105,11 @@ def main():
     outputs = dict(mean=engine.empty(nq), keep=engine.empty(nq, "uint8"), nx=engine.empty(nq),
                    ny=engine.empty(nq), nz=engine.empty(nq))
 
-    def step():
+    def step(want_stats=False):
         return sor_normals_sharded(engine, coll, shard, n_total, K_SOR, STD_MUL, K_NRM,
-                                   (0.0, 0.0, 0.0), outputs)
+                                   (0.0, 0.0, 0.0), outputs, want_stats=want_stats)
 
+    search_stats = step(want_stats=True)["stats"]  # untimed: how many queries each stage answered
     for _ in range(args.warmup):
         res = step()
     torch.cuda.synchronize()
@@ -160,7 +161,7 @@ def main():
                 "points_per_gpu": args.points,
                 "n_keep_rank0": int(res["n_keep"]),
                 "threshold": res["thr"],
-                "search_stats_rank0": dict(zip(("grid_tile", "grid_ring", "brute"), res["stats"])),
+                "search_stats_rank0": dict(zip(("cell_walk", "wave_retry", "brute"), search_stats)),
             },
             "roofline": {
                 "bound": "hbm",

@@ -204,6 +204,15 @@ int pcrs_sor_threshold_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float st
 int pcrs_sor_mask_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float thr, uint8_t *dkeep,
                       size_t *n_keep);
 
+/* Threshold and mask in one call — statistical_outlier.rs:43-66: the threshold is
+ * taken over all n_all means (a multi-GPU caller passes the gathered means of the
+ * whole cloud), the mask covers the n means at dmean (its own range).  One read-back
+ * at the end returns thr, has_finite and n_keep (each nullable); with no finite mean
+ * every keep[i] is 0 (:49-51). */
+int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
+                        const float *dmean, size_t n, uint8_t *dkeep, float *thr, int *has_finite,
+                        size_t *n_keep);
+
 /* statistical_outlier_removal(cloud, k, std_mul) — statistical_outlier.rs:4-69.
  * keep[n] is the inlier mask (the caller applies PointCloud::select,
  * crates/core/src/cloud.rs:103-140); *n_keep the survivor count; *thr_out

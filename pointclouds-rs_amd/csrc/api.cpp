@@ -736,6 +736,42 @@ int pcrs_sor_mask_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float thr, ui
     return PCRS_OK;
 }
 
+// statistical_outlier.rs:43-66 without leaving the device between the statistics and the mask:
+// the threshold comes from ALL means (dmean_all), the mask covers the caller's own range (dmean).
+int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
+                        const float *dmean, size_t n, uint8_t *dkeep, float *thr, int *has_finite,
+                        size_t *n_keep) {
+    PCRS_TRY(bind_device(ctx));
+    if (thr) *thr = std::numeric_limits<float>::quiet_NaN();
+    if (has_finite) *has_finite = 0;
+    if (n_keep) *n_keep = 0;
+    if (n_all == 0) return PCRS_OK;
+    if (!dmean_all || (n && (!dmean || !dkeep)))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    const size_t sb = (pcrs_sor_stats_scalars_bytes() + 63) & ~(size_t)63;
+    const size_t wb = pcrs_sor_stats_workspace(n_all);
+    void *scratch = nullptr;
+    PCRS_TRY(pcrs_ctx_scratch(ctx, sb + 64 + wb, &scratch));
+    char *sc = reinterpret_cast<char *>(scratch);
+    unsigned long long *dcount = reinterpret_cast<unsigned long long *>(sc + sb);
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sb + 64, &pin));
+    PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb));
+    PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount));
+    PCRS_TRY(download(ctx, pin, sc, sb + 64));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    float t;
+    int ok;
+    pcrs_sor_stats_decode(pin, nullptr, &t, &ok);
+    if (ok) {
+        if (thr) *thr = t;
+        if (has_finite) *has_finite = 1;
+        if (n_keep)
+            *n_keep = (size_t)*reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(pin) + sb);
+    }
+    return PCRS_OK;
+}
+
 // statistical_outlier.rs:43-62 on host memory: strictly left-to-right f32 sums.
 static bool host_threshold(const float *mean, size_t n, float std_mul, float *thr) {
     size_t nf = 0;

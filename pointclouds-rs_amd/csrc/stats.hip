@@ -330,21 +330,45 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
     }
 }
 
-// keep[i] = mean[i] <= thr with the threshold read from device memory
+// keep[i] = mean[i] <= thr with the threshold read from device memory; four means per thread
+// where the pointers allow it, one atomic per block for the count
 __global__ __launch_bounds__(256) void mask_dev_thr_kernel(const float *mean, size_t n,
                                                            const StatsScalars *sc, uint8_t *keep,
                                                            unsigned long long *count) {
-    const float thr = sc->has_finite ? sc->thr : -__builtin_inff();
+    const bool any = sc->has_finite != 0;
+    const float thr = any ? sc->thr : -__builtin_inff();
     unsigned local = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const bool k = sc->has_finite && (mean[i] <= thr);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t done = 0;
+    if (((reinterpret_cast<uintptr_t>(mean) & 15u) == 0) &&
+        ((reinterpret_cast<uintptr_t>(keep) & 3u) == 0)) {
+        const float4 *mean4 = reinterpret_cast<const float4 *>(mean);
+        uint32_t *keep4 = reinterpret_cast<uint32_t *>(keep);
+        const size_t n4 = n / 4;
+        for (size_t i = tid; i < n4; i += stride) {
+            const float4 m = mean4[i];
+            const uint32_t k0 = any && m.x <= thr, k1 = any && m.y <= thr;
+            const uint32_t k2 = any && m.z <= thr, k3 = any && m.w <= thr;
+            keep4[i] = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
+            local += k0 + k1 + k2 + k3;
+        }
+        done = n4 * 4;
+    }
+    for (size_t i = done + tid; i < n; i += stride) {
+        const bool k = any && (mean[i] <= thr);
         keep[i] = k ? 1 : 0;
         local += k ? 1u : 0u;
     }
     if (!count) return;
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, (unsigned long long)local);
+    __shared__ unsigned wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long s = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (s) atomicAdd(count, s);
+    }
 }
 
 }  // namespace pcrs
@@ -391,9 +415,9 @@ int pcrs_launch_mask_dev_thr(pcrs_ctx *ctx, const float *mean, size_t n, const v
                              uint8_t *keep, unsigned long long *d_count) {
     if (d_count) PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(*d_count), ctx->stream));
     if (n == 0) return PCRS_OK;
-    size_t blocks = (n + 255) / 256;
-    const size_t cap = (size_t)ctx->num_cus * 8;
-    if (blocks > cap) blocks = cap;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > (size_t)ctx->num_cus) blocks = (size_t)ctx->num_cus;
+    if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(mask_dev_thr_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mean,
                        n, reinterpret_cast<const StatsScalars *>(d_scalars), keep, d_count);
     PCRS_HIP_CHECK(ctx, hipGetLastError());

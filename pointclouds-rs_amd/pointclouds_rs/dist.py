@@ -90,6 +90,18 @@ class HipEngine:
                                                        C.byref(thr), C.byref(ok)))
         return float(thr.value), bool(ok.value)
 
+    def select(self, mean_full, std_mul, mean, keep):
+        """Threshold over mean_full and mask of `mean` with a single read-back:
+        (thr, has_finite, n_keep)."""
+        thr = C.c_float()
+        ok = C.c_int()
+        nk = C.c_size_t(0)
+        self.ctx.check(self.lib.pcrs_sor_select_dev(self.ctx.handle, self._p(mean_full),
+                                                    mean_full.numel(), float(std_mul),
+                                                    self._p(mean), mean.numel(), self._p(keep),
+                                                    C.byref(thr), C.byref(ok), C.byref(nk)))
+        return float(thr.value), bool(ok.value), int(nk.value)
+
     def mask(self, mean, thr, keep, want_count=True):
         nk = C.c_size_t(0)
         self.ctx.check(self.lib.pcrs_sor_mask_dev(self.ctx.handle, self._p(mean), mean.numel(),
@@ -198,12 +210,14 @@ class Collectives:
 
 
 def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
-                        viewpoint=(0.0, 0.0, 0.0), outputs=None, algo=_ffi.ALGO_AUTO):
+                        viewpoint=(0.0, 0.0, 0.0), outputs=None, algo=_ffi.ALGO_AUTO,
+                        want_stats=False):
     """SOR + normals of a cloud whose points are sharded over ranks in index order.
 
     shard: (x, y, z) tensors of this rank's points.  Returns a dict with this rank's
     keep mask, means, normals, the global threshold and kept count of the shard.
-    `outputs` may carry preallocated tensors (mean, keep, nx, ny, nz) to avoid allocation.
+    `outputs` may carry preallocated tensors (mean, keep, nx, ny, nz) to avoid allocation;
+    `want_stats` adds the search-stage counters of this call (a device read-back).
     """
     torch = engine.torch
     world, rank = coll.world, coll.rank
@@ -228,19 +242,18 @@ def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
     try:
         engine.sor_normals_range(index, begin, nq, k_sor, k_nrm, viewpoint,
                                  mean if k_sor else None, nx, ny, nz)
-        stats = engine.index_stats(index)
+        # reading the stage counters back waits for the search: only on request
+        stats = engine.index_stats(index) if want_stats else None
     finally:
         engine.destroy_index(index)
     result = dict(mean=mean, keep=keep, nx=nx, ny=ny, nz=nz, thr=math.nan, n_keep=0, stats=stats,
                   begin=begin, end=end)
     if k_sor:
         mean_full = coll.all_gather_var(torch, mean, counts)
-        thr, ok = engine.threshold(mean_full, std_mul)
+        thr, ok, n_keep = engine.select(mean_full, std_mul, mean, keep)
         if ok:
             result["thr"] = thr
-            result["n_keep"] = engine.mask(mean, thr, keep)
-        else:
-            keep.zero_()
+            result["n_keep"] = n_keep
     return result
 
 

@@ -44,6 +44,13 @@ class CpuEngine:
         ok, thr, _, _ = self.o.sor_threshold(mean_full.numpy(), std_mul)
         return (thr if ok else float("nan")), ok
 
+    def select(self, mean_full, std_mul, mean, keep):
+        thr, ok = self.threshold(mean_full, std_mul)
+        if not ok:
+            keep.zero_()
+            return thr, ok, 0
+        return thr, ok, self.mask(mean, thr, keep)
+
     def mask(self, mean, thr, keep, want_count=True):
         k = mean.numpy() <= np.float32(thr)
         keep.copy_(torch.from_numpy(k.astype(np.uint8)))

@@ -61,3 +61,25 @@ def test_mask_matches(engine, oracle):
     ref = m <= F(thr_ref)
     assert n_keep == int(ref.sum())
     assert np.array_equal(keep.cpu().numpy().astype(bool), ref)
+
+
+@pytest.mark.parametrize("name", ["outliers", "lognormal", "tiny"] if "tiny" in cases() else ["outliers", "lognormal"])
+def test_select_equals_threshold_then_mask(engine, oracle, name):
+    """pcrs_sor_select_dev (threshold over all means, mask of a sub-range, one read-back) against
+    the two-call path, including unaligned sub-ranges (the vectorised body needs 16-byte means)."""
+    m = cases()[name]
+    ok_ref, thr_ref, _, _ = oracle.sor_threshold(m, 1.0)
+    d = engine.from_numpy(m)
+    for b, c in ((0, len(m)), (1, 1001), (4096, 12345), (len(m) - 7, 7)):
+        sub = d[b:b + c]
+        keep = engine.empty(c + 3, "uint8")[3:] if b % 2 else engine.empty(c, "uint8")
+        thr, ok, n_keep = engine.select(d, 1.0, sub, keep)
+        assert ok == ok_ref and F(thr).view(np.uint32) == F(thr_ref).view(np.uint32)
+        ref = m[b:b + c] <= F(thr_ref)
+        assert n_keep == int(ref.sum())
+        assert np.array_equal(keep.cpu().numpy().astype(bool), ref)
+    nan = engine.from_numpy(np.full(1000, np.inf, dtype=F))
+    keep = engine.empty(1000, "uint8")
+    keep.fill_(1)
+    thr, ok, n_keep = engine.select(nan, 1.0, nan, keep)
+    assert not ok and np.isnan(thr) and n_keep == 0 and not keep.cpu().numpy().any()

@@ -170,7 +170,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None,
-                "kernel": "neighbour search + fused SOR mean / PCA normal",
+                "kernel": "knn_cell_kernel<17, true>: neighbour search over every query, fused with the SOR "
+                          "mean and the covariance of the PCA normal",
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_launches": launches,
                 "algorithmic_bytes_per_launch": BYTES_PER_POINT * nq,

@@ -96,6 +96,21 @@ struct TopK {
     }
 };
 
+// Adds the per-thread counts of a 256-thread block to *total with ONE atomic per block (atomics
+// on a single address serialise: a per-wave add from thousands of waves costs tens of
+// microseconds).  Every thread of the block must call it.
+__device__ __forceinline__ void block_count_add(unsigned local, unsigned long long *total) {
+    __shared__ unsigned pcrs_block_wsum[4];
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0) pcrs_block_wsum[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0 && total) {
+        const unsigned long long s = (unsigned long long)pcrs_block_wsum[0] + pcrs_block_wsum[1] +
+                                     pcrs_block_wsum[2] + pcrs_block_wsum[3];
+        if (s) atomicAdd(total, s);
+    }
+}
+
 // Neighbour accessors for the consumers: `for_each(c, f)` calls f(j, key_j, payload_j) for j < c in
 // order; `fetch(key, payload, x, y, z)` yields the neighbour's coordinates.
 template <int K>

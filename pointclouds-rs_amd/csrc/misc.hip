@@ -290,9 +290,7 @@ __global__ __launch_bounds__(256) void count_mask_kernel(const uint32_t *count, 
         keep[i] = k ? 1 : 0;
         local += k ? 1u : 0u;
     }
-    if (!total) return;
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, (unsigned long long)local);
+    block_count_add(local, total);
 }
 }  // namespace pcrs
 

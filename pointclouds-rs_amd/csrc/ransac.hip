@@ -89,8 +89,7 @@ __global__ __launch_bounds__(256) void plane_mask_kernel(const float *x, const f
         mask[i] = in ? 1 : 0;
         local += in ? 1u : 0u;
     }
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, (unsigned long long)local);
+    block_count_add(local, total);
 }
 
 }  // namespace pcrs

@@ -61,13 +61,30 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const float *x, const fl
             hi[a] = max(hi[a], __shfl_down(hi[a], off, 64));
         }
     for (int off = 32; off > 0; off >>= 1) nv += __shfl_down(nv, off, 64);
-    if ((threadIdx.x & 63) == 0 && nv) {
+    // one partial per block, reduced by the host (which waits for the bounds anyway): atomics of
+    // every wave on the same seven words would serialise
+    __shared__ int slo[3][4], shi[3][4];
+    __shared__ unsigned snv[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&bounds->lo[a], lo[a]);
-            atomicMax(&bounds->hi[a], hi[a]);
+            slo[a][wave] = lo[a];
+            shi[a][wave] = hi[a];
         }
-        atomicAdd(&bounds->nvalid, nv);
+        snv[wave] = nv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        VoxelBounds b;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = min(min(slo[a][0], slo[a][1]), min(slo[a][2], slo[a][3]));
+            b.hi[a] = max(max(shi[a][0], shi[a][1]), max(shi[a][2], shi[a][3]));
+        }
+        b.nvalid = snv[0] + snv[1] + snv[2] + snv[3];
+        b.pad = 0;
+        bounds[blockIdx.x] = b;
     }
 }
 
@@ -176,26 +193,33 @@ int pcrs_cell_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z
     const uint32_t un = (uint32_t)n;
     DevBuf dbounds;
     for (int a = 0; a < 3; ++a) PCRS_HIP_CHECK(ctx, cs->k[a].alloc(ctx, n * sizeof(int)));
-    PCRS_HIP_CHECK(ctx, dbounds.alloc(ctx, sizeof(VoxelBounds)));
-    void *pin = nullptr;
-    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(VoxelBounds) + 64, &pin));
-    VoxelBounds *hb = reinterpret_cast<VoxelBounds *>(pin);
-    for (int a = 0; a < 3; ++a) {
-        hb->lo[a] = INT_MAX;
-        hb->hi[a] = INT_MIN;
-    }
-    hb->nvalid = 0;
-    hb->pad = 0;
-    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dbounds.p, hb, sizeof(VoxelBounds), hipMemcpyHostToDevice,
-                                       ctx->stream));
     size_t blocks = (n + 255) / 256;
-    if (blocks > (size_t)ctx->num_cus * 8) blocks = (size_t)ctx->num_cus * 8;
+    if (blocks > (size_t)ctx->num_cus * 2) blocks = (size_t)ctx->num_cus * 2;
+    PCRS_HIP_CHECK(ctx, dbounds.alloc(ctx, blocks * sizeof(VoxelBounds)));
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, blocks * sizeof(VoxelBounds) + 64, &pin));
+    VoxelBounds *parts = reinterpret_cast<VoxelBounds *>(pin);
     hipLaunchKernelGGL(voxel_key_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, y, z,
                        un, scale, multiply, cs->k[0].as<int>(), cs->k[1].as<int>(),
                        cs->k[2].as<int>(), dbounds.as<VoxelBounds>());
-    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hb, dbounds.p, sizeof(VoxelBounds), hipMemcpyDeviceToHost,
-                                       ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(parts, dbounds.p, blocks * sizeof(VoxelBounds),
+                                       hipMemcpyDeviceToHost, ctx->stream));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    VoxelBounds total;
+    for (int a = 0; a < 3; ++a) {
+        total.lo[a] = INT_MAX;
+        total.hi[a] = INT_MIN;
+    }
+    total.nvalid = 0;
+    for (size_t b = 0; b < blocks; ++b) {
+        if (!parts[b].nvalid) continue;
+        for (int a = 0; a < 3; ++a) {
+            total.lo[a] = std::min(total.lo[a], parts[b].lo[a]);
+            total.hi[a] = std::max(total.hi[a], parts[b].hi[a]);
+        }
+        total.nvalid += parts[b].nvalid;
+    }
+    const VoxelBounds *hb = &total;
     const uint32_t nvalid = hb->nvalid;
     cs->nvalid = nvalid;
     if (nvalid == 0) return PCRS_OK;

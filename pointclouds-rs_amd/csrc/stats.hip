@@ -32,6 +32,8 @@ struct StatsScalars {
     float sigma;
     uint32_t has_finite;
     unsigned long long nf;
+    uint32_t max_bits;  // bit pattern of the largest element of the current pass (elements are >= 0)
+    float run;          // running f32 sum between two launches of the walker
 };
 
 struct Composite {
@@ -57,36 +59,51 @@ __device__ __forceinline__ float stat_element(const float *mean, size_t n, size_
 template <int PASS>
 __global__ __launch_bounds__(256) void chunk_sums_kernel(const float *mean, size_t n,
                                                          const StatsScalars *sc, double *csum,
-                                                         uint32_t *ccnt, uint32_t nchunks) {
+                                                         uint32_t *ccnt, float *cmax,
+                                                         uint32_t nchunks) {
     const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= nchunks) return;
     const int lane = threadIdx.x & 63;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
     double s = 0.0;
     uint32_t c = 0;
+    float mx = 0.0f;
 #pragma unroll
     for (int k = 0; k < ST_PER_LANE; ++k) {
         bool fin;
         const float x = stat_element<PASS>(mean, n, (size_t)chunk * ST_CHUNK + lane * ST_PER_LANE + k, mu, &fin);
         s += (double)x;
         c += fin ? 1u : 0u;
+        if (x - x == 0.0f) mx = fmaxf(mx, x);  // a squared deviation can overflow to +inf
     }
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_down(s, off, 64);
         c += __shfl_down(c, off, 64);
+        mx = fmaxf(mx, __shfl_down(mx, off, 64));
     }
     if (lane == 0) {
         csum[chunk] = s;
         ccnt[chunk] = c;
+        cmax[chunk] = mx;
     }
 }
 
 // exclusive f64 scan of the chunk sums (in place) and the total finite count
 __global__ __launch_bounds__(1024) void chunk_scan_kernel(double *csum, const uint32_t *ccnt,
-                                                          uint32_t nchunks, StatsScalars *sc,
-                                                          int write_count) {
+                                                          const float *cmax, uint32_t nchunks,
+                                                          StatsScalars *sc, int write_count) {
     __shared__ double wsum[16];
     __shared__ unsigned long long wcnt[16];
+    __shared__ float wmax[16];
+    float mx = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) mx = fmaxf(mx, cmax[i]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) mx = fmaxf(mx, wmax[w]);
+        sc->max_bits = __float_as_uint(mx);
+    }
     __shared__ double carry_s;
     __shared__ unsigned long long carry_c;
     if (threadIdx.x == 0) {
@@ -172,38 +189,73 @@ __device__ __forceinline__ int binade_of(float s) {
     return e;
 }
 
-template <int PASS>
+// Composites of the chunks [chunk_begin, chunk_end) for W binades each (comp[chunk * W + j]
+// records the binade it was built for).  W = 1 (short sums): the binade predicted from
+// the f64 prefix.  W = 4 (long sums, walked in sections): a sequential f32 sum of millions of
+// elements drifts away from the exact prefix — it runs ahead while the elements round up to a
+// whole ulp, falls behind and finally stalls once they are below half an ulp — so the window is
+// anchored on what is known for certain: the sum never decreases (at least the binade of the
+// true running sum at the start of the section, read from sc->run) and never passes the binade in
+// which the largest element is below half an ulp.
+template <int PASS, int W>
 __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean, size_t n,
                                                               const StatsScalars *sc,
                                                               const double *cpre, Composite *comp,
-                                                              uint32_t nchunks) {
-    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (chunk >= nchunks) return;
+                                                              uint32_t chunk_begin,
+                                                              uint32_t chunk_end) {
+    const uint32_t chunk = chunk_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= chunk_end) return;
     const int lane = threadIdx.x & 63;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
-    const int e = binade_of((float)cpre[chunk]);
-    Composite f;
-    f.a0 = f.a1 = 0;
-    f.e = e;
-    f.pad = 0;
-    if (e != ST_NO_BINADE) {
+    const int pred = binade_of((float)cpre[chunk]);
+    int binades[W];
 #pragma unroll
-        for (int k = 0; k < ST_PER_LANE; ++k) {
-            bool fin;
-            const float x = stat_element<PASS>(mean, n, (size_t)chunk * ST_CHUNK + lane * ST_PER_LANE + k, mu, &fin);
-            f = compose(f, element_function(x, e));
-        }
-        // ordered tree: lane l absorbs lane l + off (the later elements)
-        for (int off = 1; off < 64; off <<= 1) {
-            Composite g;
-            g.a0 = __shfl_down(f.a0, off, 64);
-            g.a1 = __shfl_down(f.a1, off, 64);
-            g.e = e;
-            g.pad = 0;
-            if ((lane & (2 * off - 1)) == 0) f = compose(f, g);
+    for (int j = 0; j < W; ++j) binades[j] = pred == ST_NO_BINADE ? ST_NO_BINADE : pred - j;
+    if (W == 4 && pred != ST_NO_BINADE) {
+        const int emax = binade_of(__uint_as_float(sc->max_bits));
+        const int cap = emax != ST_NO_BINADE ? emax + 25 : 100;
+        const int top = min(pred + 1, cap);
+        const int floor_e = chunk_begin ? binade_of(sc->run) : ST_NO_BINADE;
+        if (floor_e == ST_NO_BINADE) {  // first section: the prefix is still a close estimate
+            for (int j = 0; j < W; ++j) binades[j] = top - j;
+        } else if (top <= floor_e + 3) {  // the sum never decreases: nothing below floor_e
+            for (int j = 0; j < W; ++j) binades[j] = floor_e + 3 - j;
+        } else {  // the prefix is far ahead (the f32 sum may have stalled): cover both ends
+            binades[0] = top;
+            binades[1] = top - 1;
+            binades[2] = floor_e + 1;
+            binades[3] = floor_e;
         }
     }
-    if (lane == 0) comp[chunk] = f;
+    float x[ST_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < ST_PER_LANE; ++k) {
+        bool fin;
+        x[k] = stat_element<PASS>(mean, n, (size_t)chunk * ST_CHUNK + lane * ST_PER_LANE + k, mu, &fin);
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        int ej = binades[j];
+        if (ej != ST_NO_BINADE && (ej < -100 || ej > 100)) ej = ST_NO_BINADE;
+        Composite f;
+        f.a0 = f.a1 = 0;
+        f.e = ej;
+        f.pad = 0;
+        if (ej != ST_NO_BINADE) {
+#pragma unroll
+            for (int k = 0; k < ST_PER_LANE; ++k) f = compose(f, element_function(x[k], ej));
+            // ordered tree: lane l absorbs lane l + off (the later elements)
+            for (int off = 1; off < 64; off <<= 1) {
+                Composite g;
+                g.a0 = __shfl_down(f.a0, off, 64);
+                g.a1 = __shfl_down(f.a1, off, 64);
+                g.e = ej;
+                g.pad = 0;
+                if ((lane & (2 * off - 1)) == 0) f = compose(f, g);
+            }
+        }
+        if (lane == 0) comp[(size_t)chunk * W + j] = f;
+    }
 }
 
 // One wave walks the chunks in order carrying the exact f32 running sum.  256 chunk composites
@@ -213,24 +265,32 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
 // leaves the binade (or was built for another one) is the first whose state fails the test: it
 // is found with a ballot, summed element by element with real f32 adds, and the scan restarts
 // behind it.
-template <int PASS>
+template <int PASS, int W>
 __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_t n,
                                                         StatsScalars *sc, const Composite *comp,
-                                                        uint32_t nchunks, float std_mul) {
+                                                        uint32_t chunk_begin, uint32_t nchunks,
+                                                        bool last, float std_mul) {
+    // walks the chunks [chunk_begin, nchunks); the state crosses launches in sc->run
     constexpr int G = 4;
     constexpr uint32_t BATCH = 64u * G;
     const int lane = threadIdx.x;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
-    float s = 0.0f;  // uniform across the wave
-    for (uint32_t base = 0; base < nchunks; base += BATCH) {
-        Composite mine[G];
+    float s = chunk_begin ? sc->run : 0.0f;  // uniform across the wave
+#ifdef PCRS_STATS_DEBUG
+    uint32_t dbg_fallbacks = 0;
+#endif
+    for (uint32_t base = chunk_begin; base < nchunks; base += BATCH) {
+        Composite mine[G][W];
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             const uint32_t ci = base + (uint32_t)lane * G + k;
-            mine[k].a0 = mine[k].a1 = 0;
-            mine[k].e = ST_NO_BINADE;
-            mine[k].pad = 0;
-            if (ci < nchunks) mine[k] = comp[ci];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                mine[k][j].a0 = mine[k][j].a1 = 0;
+                mine[k][j].e = ST_NO_BINADE;
+                mine[k][j].pad = 0;
+                if (ci < nchunks) mine[k][j] = comp[(size_t)ci * W + j];
+            }
         }
         const uint32_t lim = min(BATCH, nchunks - base);
         uint32_t pos = 0;
@@ -247,13 +307,16 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                 Composite u;
                 u.e = e_now;
                 u.pad = 0;
+                u.a0 = u.a1 = ST_SAT;
                 if (ci < pos) {
                     u.a0 = u.a1 = 0;
-                } else if (e_now != ST_NO_BINADE && mine[k].e == e_now && ci < lim) {
-                    u.a0 = mine[k].a0;
-                    u.a1 = mine[k].a1;
-                } else {
-                    u.a0 = u.a1 = ST_SAT;
+                } else if (e_now != ST_NO_BINADE && ci < lim) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j)
+                        if (mine[k][j].e == e_now) {
+                            u.a0 = mine[k][j].a0;
+                            u.a1 = mine[k][j].a1;
+                        }
                 }
                 p[k] = (k == 0) ? u : compose(p[k - 1], u);
             }
@@ -296,6 +359,16 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                 s = __uint_as_float((bits & 0xFF800000u) | (Sj & 0x7FFFFFu));
             }
             if (first_bad < lim) {
+#ifdef PCRS_STATS_DEBUG
+                ++dbg_fallbacks;
+                if (lane == 0 && dbg_fallbacks <= 40)
+                    printf("pass %d fallback %u: chunk %u e_now %d built for %d %d %d %d\n", PASS,
+                           dbg_fallbacks, base + first_bad, e_now,
+                           comp[(size_t)(base + first_bad) * W].e,
+                           W > 1 ? comp[(size_t)(base + first_bad) * W + 1].e : 0,
+                           W > 2 ? comp[(size_t)(base + first_bad) * W + 2].e : 0,
+                           W > 3 ? comp[(size_t)(base + first_bad) * W + 3].e : 0);
+#endif
                 // element-by-element f32 adds over this chunk (lane-major element order)
                 float v[ST_PER_LANE];
 #pragma unroll
@@ -317,7 +390,11 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
             pos = first_bad + 1;
         }
     }
-    if (lane == 0) {
+#ifdef PCRS_STATS_DEBUG
+    if (lane == 0) printf("pass %d: %u element-wise chunks of %u, final s %g\n", PASS, dbg_fallbacks, nchunks, s);
+#endif
+    if (lane == 0) sc->run = s;
+    if (lane == 0 && last) {
         const float nn = (float)sc->nf;  // finite_dists.len() as f32
         if (PASS == 1) {
             sc->mu = s / nn;
@@ -375,6 +452,31 @@ __global__ __launch_bounds__(256) void mask_dev_thr_kernel(const float *mean, si
 
 using namespace pcrs;
 
+static int stats_window(size_t n);
+
+// Composites + walk of one pass.  Short sums: one launch each.  Long sums: sections of 4096
+// chunks (1 M elements), the composites of a section built once the true running sum at its start
+// is known (everything is queued on the stream; nothing comes back to the host).
+template <int PASS>
+static void run_pass(pcrs_ctx *ctx, int W, const float *dmean, size_t n, StatsScalars *sc,
+                     const double *csum, Composite *comp, uint32_t nchunks, float std_mul) {
+    if (W == 1) {
+        hipLaunchKernelGGL((chunk_composite_kernel<PASS, 1>), dim3((nchunks + 3) / 4), dim3(256), 0,
+                           ctx->stream, dmean, n, sc, csum, comp, 0u, nchunks);
+        hipLaunchKernelGGL((stats_walk_kernel<PASS, 1>), dim3(1), dim3(64), 0, ctx->stream, dmean, n,
+                           sc, comp, 0u, nchunks, true, std_mul);
+        return;
+    }
+    constexpr uint32_t kSection = 4096;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += kSection) {
+        const uint32_t c1 = c0 + kSection < nchunks ? c0 + kSection : nchunks;
+        hipLaunchKernelGGL((chunk_composite_kernel<PASS, 4>), dim3((c1 - c0 + 3) / 4), dim3(256), 0,
+                           ctx->stream, dmean, n, sc, csum, comp, c0, c1);
+        hipLaunchKernelGGL((stats_walk_kernel<PASS, 4>), dim3(1), dim3(64), 0, ctx->stream, dmean, n,
+                           sc, comp, c0, c1, c1 == nchunks, std_mul);
+    }
+}
+
 // Runs both passes; leaves {mu, thr, sigma, has_finite, nf} in *d_scalars (device).  No host sync.
 int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
                           void *d_scalars, void *d_work, size_t work_bytes) {
@@ -384,29 +486,35 @@ int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "stats workspace too small");
     StatsScalars *sc = reinterpret_cast<StatsScalars *>(d_scalars);
     char *w = reinterpret_cast<char *>(d_work);
+    const int W = stats_window(n);
     double *csum = reinterpret_cast<double *>(w);
     Composite *comp = reinterpret_cast<Composite *>(w + (size_t)nchunks * sizeof(double));
-    uint32_t *ccnt = reinterpret_cast<uint32_t *>(w + (size_t)nchunks * (sizeof(double) + sizeof(Composite)));
+    char *after = w + (size_t)nchunks * (sizeof(double) + (size_t)W * sizeof(Composite));
+    uint32_t *ccnt = reinterpret_cast<uint32_t *>(after);
+    float *cmax = reinterpret_cast<float *>(after + (size_t)nchunks * sizeof(uint32_t));
     PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
     if (n == 0) return PCRS_OK;
     const dim3 cgrid((nchunks + 3) / 4), cblock(256);
     // pass 1: mean
-    hipLaunchKernelGGL(chunk_sums_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, nchunks);
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, nchunks, sc, 1);
-    hipLaunchKernelGGL(chunk_composite_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, comp, nchunks);
-    hipLaunchKernelGGL(stats_walk_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, dmean, n, sc, comp, nchunks, std_mul);
+    hipLaunchKernelGGL(chunk_sums_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, cmax, nchunks, sc, 1);
+    run_pass<1>(ctx, W, dmean, n, sc, csum, comp, nchunks, std_mul);
     // pass 2: variance
-    hipLaunchKernelGGL(chunk_sums_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, nchunks);
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, nchunks, sc, 0);
-    hipLaunchKernelGGL(chunk_composite_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, comp, nchunks);
-    hipLaunchKernelGGL(stats_walk_kernel<2>, dim3(1), dim3(64), 0, ctx->stream, dmean, n, sc, comp, nchunks, std_mul);
+    hipLaunchKernelGGL(chunk_sums_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, cmax, nchunks, sc, 0);
+    run_pass<2>(ctx, W, dmean, n, sc, csum, comp, nchunks, std_mul);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
 
+// Binades per chunk composite: a sum of more than a few million similar elements can stall
+// below the exact prefix, which the window of four binades follows; short sums use one.
+static int stats_window(size_t n) { return n > (size_t)4 << 20 ? 4 : 1; }
+
 size_t pcrs_sor_stats_workspace(size_t n) {
     const size_t nchunks = (n + ST_CHUNK - 1) / ST_CHUNK + 1;
-    return nchunks * (sizeof(double) + sizeof(Composite) + sizeof(uint32_t)) + 64;
+    return nchunks * (sizeof(double) + (size_t)stats_window(n) * sizeof(Composite) +
+                      sizeof(uint32_t) + sizeof(float)) + 64;
 }
 
 size_t pcrs_sor_stats_scalars_bytes() { return sizeof(StatsScalars); }

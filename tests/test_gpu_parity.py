@@ -465,6 +465,56 @@ def test_query_subrange_equals_full(oracle):
         eng.destroy_index(ix)
 
 
+def test_large_cloud_parity(oracle):
+    """6 M points (the benchmark's per-GPU size times six): means, threshold and mask bit-exact,
+    normals within tolerance on a sample; also the one-level (global-atomic) sort, which grids
+    beyond 33 M cells fall back to, must give the same answers."""
+    import os
+
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine(0)
+    n = 6_000_000
+    side = np.float32(100.0 * 6 ** (1.0 / 3.0))
+    cols_h = [(gen.uniform01(77, n, a) * side).astype(F) for a in range(3)]
+    cols = [eng.from_numpy(c) for c in cols_h]
+    rmean = oracle.sor_mean_dist(*cols_h, 16, algo=1, threads=0)
+    ok_ref, thr_ref, _, _ = oracle.sor_threshold(rmean, 1.0)
+    results = []
+    for sort in ("two-level", "atomic"):
+        if sort == "atomic":
+            os.environ["PCRS_GRID_SORT"] = "atomic"
+        try:
+            ix = eng.build_index(*cols, 17)
+        finally:
+            os.environ.pop("PCRS_GRID_SORT", None)
+        mean = eng.empty(n); nx = eng.empty(n); ny = eng.empty(n); nz = eng.empty(n)
+        eng.sor_normals_range(ix, 0, n, 16, 16, (0.0, 0.0, 0.0), mean, nx, ny, nz)
+        keep = eng.empty(n, "uint8")
+        thr, ok, n_keep = eng.select(mean, 1.0, mean, keep)
+        eng.destroy_index(ix)
+        assert np.array_equal(mean.cpu().numpy().view(np.uint32), rmean.view(np.uint32)), sort
+        assert ok == ok_ref and F(thr).view(np.uint32) == F(thr_ref).view(np.uint32)
+        k = keep.cpu().numpy().astype(bool)
+        assert np.array_equal(k, rmean <= F(thr_ref)) and n_keep == int(k.sum())
+        results.append([t.cpu().numpy() for t in (nx, ny, nz)])
+    for a, b in zip(*results):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # normals of a slice against the oracle (a whole-cloud oracle run would take minutes)
+    sl = slice(1_000_000, 1_020_000)
+    idx, _, _, _ = oracle.knn(*cols_h, cols_h[0][sl], cols_h[1][sl], cols_h[2][sl], 16, algo=1)
+    assert idx.shape == (20000, 16)
+    pts = np.stack(cols_h, 1)
+    nb = pts[idx]                                   # (20000, 16, 3)
+    c = nb.mean(1, dtype=np.float64)
+    d = nb - c[:, None, :]
+    cov = np.einsum("nki,nkj->nij", d, d)
+    w, v = np.linalg.eigh(cov)
+    ref = v[:, :, 0]
+    got = np.stack([r[sl] for r in results[0]], 1).astype(np.float64)
+    assert np.all(np.abs(np.abs((got * ref).sum(1)) - 1.0) < 1e-3)  # same axis (sign set by viewpoint)
+
+
 def test_search_stage_statistics():
     """The retry stages must actually be exercised by clouds with sparse outliers."""
     from pointclouds_rs import hip

@@ -83,3 +83,21 @@ def test_select_equals_threshold_then_mask(engine, oracle, name):
     keep.fill_(1)
     thr, ok, n_keep = engine.select(nan, 1.0, nan, keep)
     assert not ok and np.isnan(thr) and n_keep == 0 and not keep.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("name", ["stall20M", "lognormal6M", "tiny5M"])
+def test_threshold_bit_exact_long_sums(engine, oracle, name):
+    """Sums long enough for the sequential f32 sum to fall behind the exact sum (it stalls once
+    the elements are below half an ulp): the composites are then built for a window of binades."""
+    rng = np.random.default_rng(12)
+    if name == "stall20M":
+        m = rng.uniform(0.5, 1.5, 20_000_000).astype(F)
+    elif name == "lognormal6M":
+        m = rng.lognormal(0.0, 1.5, 6_000_000).astype(F)
+    else:
+        m = (rng.uniform(0.0, 1.0, 5_000_000) * 1e-12).astype(F)
+    m[::100003] = np.inf
+    for mul in (1.0,):
+        ok_ref, thr_ref, _, _ = oracle.sor_threshold(m, mul)
+        thr, ok = engine.threshold(engine.from_numpy(m), mul)
+        assert ok == ok_ref and F(thr).view(np.uint32) == F(thr_ref).view(np.uint32), (name, thr, thr_ref)

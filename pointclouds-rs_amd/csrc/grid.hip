@@ -292,10 +292,15 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
         const uint32_t o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
+    __shared__ uint32_t wopen[GB_THREADS / 64];
     if (lane == 63) wsum[wave] = incl;
     for (int off = 32; off > 0; off >>= 1) opened += __shfl_down(opened, off, 64);
-    if (lane == 0 && opened) atomicAdd(nonempty, opened);
+    if (lane == 0) wopen[wave] = opened;
     __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per block
+        const uint32_t o = wopen[0] + wopen[1] + wopen[2] + wopen[3];
+        if (o) atomicAdd(nonempty, o);
+    }
     uint32_t run = begin + incl - local;
     for (int w = 0; w < wave; ++w) run += wsum[w];
     for (uint32_t j = 0; j < ipt; ++j) {

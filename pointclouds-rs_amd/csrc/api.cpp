@@ -997,7 +997,9 @@ namespace {
 int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const float *cx,
                           const float *cy, const float *cz, size_t n, const float *tnx,
                           const float *tny, const float *tnz, float max_d, uint32_t *nn_idx,
-                          float *nn_d2, double *dsums, uint32_t *tgt_out, float *dist_out) {
+                          float *nn_d2, double *dsums, uint32_t *tgt_out, float *dist_out,
+                          IcpLoopState *d_state = nullptr, size_t n_source = 0,
+                          float tolerance = 0.0f) {
     KnnQuery q;
     q.qx = cx;
     q.qy = cy;
@@ -1008,7 +1010,8 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
     o.nn_d2 = nn_d2;
     PCRS_TRY(run_query(target, q, o, 1));
     return pcrs_launch_icp_reduce(ctx, mode, cx, cy, cz, n, target->x, target->y, target->z, tnx,
-                                  tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums);
+                                  tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums, d_state,
+                                  n_source, tolerance);
 }
 
 // Reorders the source spatially.  The sums of an ICP step do not depend on the order of the
@@ -1323,8 +1326,8 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
             PCRS_TRY(correspond_and_reduce(ctx, icp->target, mode, cx, cy, cz, icp->n, icp->tnx,
                                            icp->tny, icp->tnz, max_correspondence_distance,
                                            icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
-                                           icp->sums.as<double>(), nullptr, nullptr));
-            PCRS_TRY(pcrs_launch_icp_tail(ctx, mode, icp->sums.as<double>(), icp->n, tolerance, ds));
+                                           icp->sums.as<double>(), nullptr, nullptr, ds, icp->n,
+                                           tolerance));  // the reduction's last kernel runs the tail
             PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));  // icp.rs:186
         }
         iter += nb;

@@ -344,8 +344,9 @@ struct CellArgs {
     const uint32_t *qlist;
     const uint32_t *qcount;
     int R;                  // cube half-width in cells (per-lane kernels)
-    int wave_radii[4];      // cube half-widths the wave-per-query kernel tries in turn; entry 0
+    int wave_radii[5];      // cube half-widths the wave-per-query kernel tries in turn; entry 0
                             // is only for queries flagged PCRS_HEAVY_FLAG in the list
+    int n_radii;            // entries of wave_radii in use
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         // larger and larger cubes until the K-th distance is certified (the wave is uniform
         // in the query, so the escalation costs no divergence)
 #pragma unroll 1
-        for (int ri = first_radius; ri < 4 && !certified; ++ri) {
+        for (int ri = first_radius; ri < a.n_radii && !certified; ++ri) {
             const int R = a.wave_radii[ri];
             x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
             y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
@@ -1573,6 +1574,15 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.wave_radii[1] = 2;
     a.wave_radii[2] = 4;
     a.wave_radii[3] = 8;
+    a.n_radii = 4;
+    // 1-NN searches end with the whole grid as the last "cube": for the handful of queries that
+    // are left (points far from the cloud) one wave scanning every point costs less than a launch
+    // of the tiled brute-force kernel, which is then not needed at all
+    const bool wave_does_all = nn_only && ix->nvalid <= (size_t)4 << 20;
+    if (wave_does_all) {
+        a.wave_radii[4] = 1 << 20;
+        a.n_radii = 5;
+    }
     a.qmode = 2;
     a.qlist = listA;
     a.qcount = &counters[0];
@@ -1582,8 +1592,9 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     uint32_t *src = listB;
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     // stage 4: brute force over what is left
-    const int rc_bf = pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, src,
-                                         &counters[3], nq);
+    const int rc_bf = wave_does_all ? PCRS_OK
+                                    : pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out,
+                                                         kneed, src, &counters[3], nq);
     if (cov.p && rc_bf == PCRS_OK) {
         const float *cqx = q.self ? ix->x + q.out_offset : q.qx;
         const float *cqy = q.self ? ix->y + q.out_offset : q.qy;

@@ -191,10 +191,47 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
     }
 }
 
+// What the host does between two iterations of the ICP loop (icp.rs:147-188), for one thread.
+__device__ inline void icp_tail_step(int mode, const double *sums, float n_source, float tolerance,
+                                IcpLoopState *st) {
+    if (st->done) return;
+    st->num_iterations += 1u;
+    if (!(sums[0] > 0.0)) {  // icp.rs:163-165
+        st->done = 1u;
+        return;
+    }
+    const float rmse = (float)sqrt(sums[1] / sums[0]);          // icp.rs:273-282
+    const float fitness = (float)(size_t)sums[0] / n_source;    // icp.rs:170
+    st->last_rmse = rmse;
+    st->last_fitness = fitness;
+    if (fabsf(st->prev_rmse - rmse) < tolerance) {  // icp.rs:173-176
+        st->converged = 1u;
+        st->done = 1u;
+        return;
+    }
+    st->prev_rmse = rmse;
+    float r[9], t[3];
+    if (mode == PCRS_ICP_POINT_TO_PLANE)
+        pcrs_math::solve_plane(sums, r, t);
+    else
+        pcrs_math::solve_point(sums, r, t);
+    for (int i = 0; i < 9; ++i) st->inc_r[i] = r[i];
+    for (int i = 0; i < 3; ++i) st->inc_t[i] = t[i];
+    float cr[9], ct[3], nr[9], nt[3];
+    for (int i = 0; i < 9; ++i) cr[i] = st->cum_r[i];
+    for (int i = 0; i < 3; ++i) ct[i] = st->cum_t[i];
+    pcrs_math::compose(cr, ct, r, t, nr, nt);  // icp.rs:183
+    for (int i = 0; i < 9; ++i) st->cum_r[i] = nr[i];
+    for (int i = 0; i < 3; ++i) st->cum_t[i] = nt[i];
+}
+
+
 // Stage 2: 32 groups of threads fold the block partials (group g takes blocks g, g+32, ... in
 // order), then 32 threads fold the groups in order: a fixed summation tree, a few microseconds.
+// With a loop state, thread 0 then runs the tail of the iteration on the fresh sums.
 __global__ __launch_bounds__(1024) void icp_final_kernel(const double *partials, uint32_t nblocks,
-                                                         double *sums) {
+                                                         double *sums, int mode, float n_source,
+                                                         float tolerance, IcpLoopState *st) {
     __shared__ double grp[32][PCRS_ICP_NSUMS + 1];
     const int i = threadIdx.x & 31, gidx = threadIdx.x >> 5;
     double v = 0.0;
@@ -205,6 +242,11 @@ __global__ __launch_bounds__(1024) void icp_final_kernel(const double *partials,
         double t = 0.0;
         for (int q = 0; q < 32; ++q) t += grp[q][threadIdx.x];
         sums[threadIdx.x] = t;
+    }
+    if (st) {
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) icp_tail_step(mode, sums, n_source, tolerance, st);
     }
 }
 
@@ -312,35 +354,7 @@ namespace pcrs {
 
 __global__ void icp_tail_kernel(int mode, const double *sums, float n_source, float tolerance,
                                 IcpLoopState *st) {
-    if (st->done) return;
-    st->num_iterations += 1u;
-    if (!(sums[0] > 0.0)) {  // icp.rs:163-165
-        st->done = 1u;
-        return;
-    }
-    const float rmse = (float)sqrt(sums[1] / sums[0]);          // icp.rs:273-282
-    const float fitness = (float)(size_t)sums[0] / n_source;    // icp.rs:170
-    st->last_rmse = rmse;
-    st->last_fitness = fitness;
-    if (fabsf(st->prev_rmse - rmse) < tolerance) {  // icp.rs:173-176
-        st->converged = 1u;
-        st->done = 1u;
-        return;
-    }
-    st->prev_rmse = rmse;
-    float r[9], t[3];
-    if (mode == PCRS_ICP_POINT_TO_PLANE)
-        pcrs_math::solve_plane(sums, r, t);
-    else
-        pcrs_math::solve_point(sums, r, t);
-    for (int i = 0; i < 9; ++i) st->inc_r[i] = r[i];
-    for (int i = 0; i < 3; ++i) st->inc_t[i] = t[i];
-    float cr[9], ct[3], nr[9], nt[3];
-    for (int i = 0; i < 9; ++i) cr[i] = st->cum_r[i];
-    for (int i = 0; i < 3; ++i) ct[i] = st->cum_t[i];
-    pcrs_math::compose(cr, ct, r, t, nr, nt);  // icp.rs:183
-    for (int i = 0; i < 9; ++i) st->cum_r[i] = nr[i];
-    for (int i = 0; i < 3; ++i) st->cum_t[i] = nt[i];
+    icp_tail_step(mode, sums, n_source, tolerance, st);
 }
 
 __global__ __launch_bounds__(256) void transform_state_kernel(float *x, float *y, float *z, size_t n,
@@ -383,10 +397,12 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            const float *cz, size_t n, const float *tx, const float *ty,
                            const float *tz, const float *tnx, const float *tny, const float *tnz,
                            const uint32_t *nn_idx, const float *nn_d2, float max_d,
-                           uint32_t *tgt_idx_out, float *dist_out, double *d_sums) {
+                           uint32_t *tgt_idx_out, float *dist_out, double *d_sums,
+                           IcpLoopState *d_state, size_t n_source, float tolerance) {
     if (n == 0) {
         PCRS_HIP_CHECK(ctx,
                        hipMemsetAsync(d_sums, 0, PCRS_ICP_NSUMS * sizeof(double), ctx->stream));
+        if (d_state) return pcrs_launch_icp_tail(ctx, mode, d_sums, n_source, tolerance, d_state);
         return PCRS_OK;
     }
     size_t blocks = (n + ICP_THREADS - 1) / ICP_THREADS;
@@ -404,7 +420,7 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            dim3(ICP_THREADS), 0, ctx->stream, cx, cy, cz, (uint32_t)n, tx, ty, tz,
                            tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials);
     hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, partials,
-                       (uint32_t)blocks, d_sums);
+                       (uint32_t)blocks, d_sums, mode, (float)n_source, tolerance, d_state);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

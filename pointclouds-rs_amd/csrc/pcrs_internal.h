@@ -256,7 +256,8 @@ struct IcpLoopState {
     uint32_t done;  // loop has ended (converged or no correspondences): later iterations are no-ops
     uint32_t num_iterations;
 };
-// After the sums of an iteration are in d_sums: metrics, convergence test, solve, compose.
+// After the sums of an iteration are in d_sums: metrics, convergence test, solve, compose
+// (pcrs_launch_icp_reduce does the same inside its last kernel when given a loop state).
 int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, size_t n_source,
                          float tolerance, IcpLoopState *d_state);
 // cur = inc(cur) with the increment read from the device state; no-op once the loop is done.
@@ -266,7 +267,9 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            const float *cz, size_t n, const float *tx, const float *ty,
                            const float *tz, const float *tnx, const float *tny, const float *tnz,
                            const uint32_t *nn_idx, const float *nn_d2, float max_d,
-                           uint32_t *tgt_idx_out, float *dist_out, double *d_sums);
+                           uint32_t *tgt_idx_out, float *dist_out, double *d_sums,
+                           IcpLoopState *d_state = nullptr, size_t n_source = 0,
+                           float tolerance = 0.0f);
 // SOR global statistics with the reference's left-to-right f32 summation, on the device (stats.hip)
 size_t pcrs_sor_stats_workspace(size_t n);
 size_t pcrs_sor_stats_scalars_bytes();

@@ -344,6 +344,27 @@ def test_correspondences_and_step_sums(hip, oracle, algo):
     icp.close()
 
 
+def test_correspondences_far_and_crowded_queries(hip, oracle):
+    """1-NN queries that leave the 27-cell cube: far outside the cloud (escalating radii up to
+    the whole grid), inside a crowded cell (handed to the wave kernel), non-finite."""
+    tx, ty, tz = gen.uniform_cloud(30000, 3, 0, 10)
+    blob = np.random.default_rng(5).normal(5.0, 1e-3, size=(6000, 3)).astype(F)
+    tx, ty, tz = np.concatenate([tx, blob[:, 0]]), np.concatenate([ty, blob[:, 1]]), np.concatenate([tz, blob[:, 2]])
+    q = np.concatenate([
+        np.random.default_rng(6).uniform(-500, 500, size=(3000, 3)),
+        np.random.default_rng(7).normal(5.0, 2e-3, size=(3000, 3)),
+        np.random.default_rng(8).uniform(0, 10, size=(3000, 3)),
+        np.array([[np.nan, 0, 0], [1e30, 1e30, -1e30], [5, 5, np.inf]]),
+    ]).astype(F)
+    ix = hip.Index(tx, ty, tz, k_hint=1, algo=2)
+    for max_d in (np.inf, 3.0):
+        t, d, n = ix.find_correspondences(q[:, 0], q[:, 1], q[:, 2], max_d)
+        rt, rd, rn = oracle.find_correspondences(q[:, 0], q[:, 1], q[:, 2], tx, ty, tz, max_d, algo=1)
+        assert n == rn and np.array_equal(t, rt)
+        assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+    ix.close()
+
+
 @pytest.mark.parametrize("n", [1000, 20000], ids=["unordered", "cell-ordered"])
 def test_icp_current_keeps_caller_order(hip, oracle, n):
     """Large sources are reordered spatially inside the ICP object; the caller never sees it."""

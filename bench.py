@@ -138,8 +138,10 @@ def main():
     if args.icp_iters > 0 and rank == 0:
         icp_line = bench_icp(engine, synth, args.icp_iters)
     stages_line = None
+    host_line = None
     if not args.no_stages and rank == 0 and world == 1:
         stages_line = bench_stages(engine, shard, args.points)
+        host_line = bench_host_call(full_host)
 
     if rank == 0:
         out = {
@@ -183,6 +185,8 @@ def main():
             out["icp"] = icp_line
         if stages_line:
             out["other_stages"] = stages_line
+        if host_line:
+            out["host_buffer_call"] = host_line
         out["roofline"]["traffic"] = pmc_traffic()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(*full_host)
@@ -207,6 +211,25 @@ def pmc_traffic():
         if "knn_cell_kernel<17, true>" in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
             return (counters["FETCH_SIZE"]["mean_per_launch"] + counters["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
     return None
+
+
+def bench_host_call(cols):
+    """The same workload through the host-pointer entry point (what a Rust caller binds):
+    pcrs_sor_normals with H2D of the columns and D2H of mask + normals inside the call.  Never
+    the headline value; it shows what PCIe adds."""
+    import numpy as np
+
+    from pointclouds_rs import hip
+
+    x, y, z = cols
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        keep, n_keep, thr, nrm = hip.sor_normals(x, y, z, K_SOR, STD_MUL, K_NRM)
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts[1:]))
+    return {"entry_point": "pcrs_sor_normals (pageable host buffers)", "ms": dt * 1e3,
+            "Mpoints_per_s": len(x) / dt / 1e6, "n_keep": int(n_keep)}
 
 
 def bench_stages(engine, cols, n):

@@ -131,7 +131,7 @@ int bind_device(pcrs_ctx *ctx) {
 }
 
 int upload(pcrs_ctx *ctx, DevBuf &dst, const float *src, size_t n) {
-    PCRS_HIP_CHECK(ctx, dst.alloc(n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, dst.alloc(ctx, n * sizeof(float)));
     if (n) PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dst.p, src, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     return PCRS_OK;
 }
@@ -375,9 +375,9 @@ int pcrs_knn_batch(pcrs_index *index, const float *qx, const float *qy, const fl
     PCRS_TRY(upload(ctx, dqy, qy, n));
     PCRS_TRY(upload(ctx, dqz, qz, n));
     const size_t nk = n * (size_t)k;
-    if (idx) PCRS_HIP_CHECK(ctx, didx.alloc(nk * sizeof(uint32_t)));
-    if (dist) PCRS_HIP_CHECK(ctx, ddist.alloc(nk * sizeof(float)));
-    if (count) PCRS_HIP_CHECK(ctx, dcount.alloc(n * sizeof(uint32_t)));
+    if (idx) PCRS_HIP_CHECK(ctx, didx.alloc(ctx, nk * sizeof(uint32_t)));
+    if (dist) PCRS_HIP_CHECK(ctx, ddist.alloc(ctx, nk * sizeof(float)));
+    if (count) PCRS_HIP_CHECK(ctx, dcount.alloc(ctx, n * sizeof(uint32_t)));
     PCRS_TRY(pcrs_knn_batch_dev(index, dqx.as<float>(), dqy.as<float>(), dqz.as<float>(), n, k,
                                 idx ? didx.as<uint32_t>() : nullptr,
                                 dist ? ddist.as<float>() : nullptr,
@@ -480,8 +480,8 @@ int pcrs_radius_outlier(pcrs_ctx *ctx, const float *x, const float *y, const flo
     PCRS_TRY(upload(ctx, dx, x, n));
     PCRS_TRY(upload(ctx, dy, y, n));
     PCRS_TRY(upload(ctx, dz, z, n));
-    PCRS_HIP_CHECK(ctx, dkeep.alloc(n));
-    PCRS_HIP_CHECK(ctx, dcount.alloc(n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, dkeep.alloc(ctx, n));
+    PCRS_HIP_CHECK(ctx, dcount.alloc(ctx, n * sizeof(uint32_t)));
     size_t kept = 0;
     PCRS_TRY(pcrs_radius_outlier_dev(ctx, dx.as<float>(), dy.as<float>(), dz.as<float>(), n, radius,
                                      min_neighbors, dkeep.as<uint8_t>(), dcount.as<uint32_t>(),
@@ -503,7 +503,7 @@ int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const
     PCRS_TRY(upload(ctx, dqx, qx, n));
     PCRS_TRY(upload(ctx, dqy, qy, n));
     PCRS_TRY(upload(ctx, dqz, qz, n));
-    PCRS_HIP_CHECK(ctx, dcount.alloc(n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, dcount.alloc(ctx, n * sizeof(uint32_t)));
     PCRS_TRY(pcrs_radius_count_dev(index, dqx.as<float>(), dqy.as<float>(), dqz.as<float>(), n,
                                    radius, dcount.as<uint32_t>()));
     PCRS_TRY(download(ctx, count, dcount.p, n * sizeof(uint32_t)));
@@ -542,7 +542,7 @@ int pcrs_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const f
     float *dst[3] = {out_x, out_y, out_z};
     for (int a = 0; a < 3; ++a) {
         PCRS_TRY(upload(ctx, d[a], src[a], n));
-        PCRS_HIP_CHECK(ctx, o[a].alloc(n * sizeof(float)));
+        PCRS_HIP_CHECK(ctx, o[a].alloc(ctx, n * sizeof(float)));
     }
     size_t nv = 0;
     PCRS_TRY(pcrs_launch_voxel_downsample(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(),
@@ -580,8 +580,8 @@ int pcrs_ransac_plane_samples(pcrs_ctx *ctx, const float *x, const float *y, con
     DevBuf d[3], dmask, dsamp;
     const float *src[3] = {x, y, z};
     for (int a = 0; a < 3; ++a) PCRS_TRY(upload(ctx, d[a], src[a], n));
-    PCRS_HIP_CHECK(ctx, dmask.alloc(n));
-    PCRS_HIP_CHECK(ctx, dsamp.alloc(3 * n_samples * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, dmask.alloc(ctx, n));
+    PCRS_HIP_CHECK(ctx, dsamp.alloc(ctx, 3 * n_samples * sizeof(uint32_t)));
     if (n_samples)
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dsamp.p, samples, 3 * n_samples * sizeof(uint32_t),
                                            hipMemcpyHostToDevice, ctx->stream));
@@ -624,8 +624,8 @@ int pcrs_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y, const 
     DevBuf d[3], doff, didx;
     const float *src[3] = {x, y, z};
     for (int a = 0; a < 3; ++a) PCRS_TRY(upload(ctx, d[a], src[a], n));
-    PCRS_HIP_CHECK(ctx, doff.alloc((n + 1) * sizeof(uint32_t)));
-    PCRS_HIP_CHECK(ctx, didx.alloc(n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, doff.alloc(ctx, (n + 1) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, didx.alloc(ctx, n * sizeof(uint32_t)));
     size_t nc = 0, ni = 0;
     PCRS_TRY(pcrs_launch_euclidean_cluster(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(),
                                            n, distance_threshold, min_size, max_size,
@@ -832,21 +832,29 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
         pcrs_index_destroy(ix);
         return code;
     };
-    if (run_sor && dmean.alloc(n * sizeof(float)) != hipSuccess)
+    if (run_sor && dmean.alloc(ctx, n * sizeof(float)) != hipSuccess)
         return fail(pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed"));
-    if (run_n && (dnx.alloc(n * sizeof(float)) != hipSuccess ||
-                  dny.alloc(n * sizeof(float)) != hipSuccess ||
-                  dnz.alloc(n * sizeof(float)) != hipSuccess))
+    if (run_n && (dnx.alloc(ctx, n * sizeof(float)) != hipSuccess ||
+                  dny.alloc(ctx, n * sizeof(float)) != hipSuccess ||
+                  dnz.alloc(ctx, n * sizeof(float)) != hipSuccess))
         return fail(pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed"));
     rc = pcrs_sor_normals_dev(ix, 0, n, run_sor ? k_sor : 0, run_n ? k_normals : 0, viewpoint,
                               run_sor ? dmean.as<float>() : nullptr,
                               run_n ? dnx.as<float>() : nullptr, run_n ? dny.as<float>() : nullptr,
                               run_n ? dnz.as<float>() : nullptr);
     if (rc != PCRS_OK) return fail(rc);
-    std::vector<float> hmean;
+    // statistics and mask stay on the device (statistical_outlier.rs:43-66): only the mask, the
+    // normals and three scalars cross PCIe
+    DevBuf dkeep;
+    float thr = std::numeric_limits<float>::quiet_NaN();
+    int has_finite = 0;
+    size_t kept = 0;
     if (run_sor) {
-        hmean.resize(n);
-        rc = download(ctx, hmean.data(), dmean.p, n * sizeof(float));
+        if (dkeep.alloc(ctx, n) != hipSuccess)
+            return fail(pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed"));
+        rc = pcrs_sor_select_dev(ctx, dmean.as<float>(), n, std_mul, dmean.as<float>(), n,
+                                 dkeep.as<uint8_t>(), &thr, &has_finite, &kept);
+        if (rc == PCRS_OK) rc = download(ctx, keep, dkeep.p, n);
         if (rc != PCRS_OK) return fail(rc);
     }
     if (run_n) {
@@ -859,18 +867,8 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
         return fail(pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed"));
     pcrs_index_destroy(ix);
     if (run_sor) {
-        float thr;
-        size_t kept = 0;
-        if (!host_threshold(hmean.data(), n, std_mul, &thr)) {  // :49-51
-            std::memset(keep, 0, n);
-        } else {
-            if (thr_out) *thr_out = thr;
-            for (size_t i = 0; i < n; ++i) {  // :64-66
-                keep[i] = hmean[i] <= thr ? 1 : 0;
-                kept += keep[i];
-            }
-        }
-        if (n_keep) *n_keep = kept;
+        if (has_finite && thr_out) *thr_out = thr;
+        if (n_keep) *n_keep = kept;  // no finite mean: every keep[i] is 0 (:49-51)
     }
     return PCRS_OK;
 }
@@ -903,7 +901,7 @@ int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size
     pcrs_index *ix = nullptr;
     PCRS_TRY(pcrs_index_build(ctx, x, y, z, n, k + 1, PCRS_ALGO_AUTO, &ix));
     DevBuf dmean;
-    int rc = dmean.alloc(n * sizeof(float)) == hipSuccess
+    int rc = dmean.alloc(ctx, n * sizeof(float)) == hipSuccess
                  ? PCRS_OK
                  : pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed");
     if (rc == PCRS_OK) rc = pcrs_sor_mean_dist_dev(ix, 0, n, k, dmean.as<float>());
@@ -1025,9 +1023,9 @@ int icp_order_source(pcrs_icp *icp) {
     int rc = PCRS_OK;
     if (tmp->algo == PCRS_ALGO_GRID && tmp->nvalid == n) {  // all finite
         for (int a = 0; a < 3 && rc == PCRS_OK; ++a)
-            if (icp->ord_s[a].alloc(n * sizeof(float)) != hipSuccess)
+            if (icp->ord_s[a].alloc(ctx, n * sizeof(float)) != hipSuccess)
                 rc = pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed");
-        if (rc == PCRS_OK && icp->perm.alloc(n * sizeof(uint32_t)) != hipSuccess)
+        if (rc == PCRS_OK && icp->perm.alloc(ctx, n * sizeof(uint32_t)) != hipSuccess)
             rc = pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed");
         if (rc == PCRS_OK)
             rc = pcrs_grid_sorted_columns(tmp, icp->ord_s[0].as<float>(), icp->ord_s[1].as<float>(),
@@ -1048,11 +1046,11 @@ int icp_order_source(pcrs_icp *icp) {
 int icp_alloc_work(pcrs_icp *icp) {
     pcrs_ctx *ctx = icp->ctx;
     const size_t n = icp->n;
-    for (int a = 0; a < 3; ++a) PCRS_HIP_CHECK(ctx, icp->cur[a].alloc(n * sizeof(float)));
-    PCRS_HIP_CHECK(ctx, icp->nn_idx.alloc(n * sizeof(uint32_t)));
-    PCRS_HIP_CHECK(ctx, icp->nn_d2.alloc(n * sizeof(float)));
-    PCRS_HIP_CHECK(ctx, icp->sums.alloc(PCRS_ICP_NSUMS * sizeof(double)));
-    PCRS_HIP_CHECK(ctx, icp->state.alloc(sizeof(IcpLoopState)));
+    for (int a = 0; a < 3; ++a) PCRS_HIP_CHECK(ctx, icp->cur[a].alloc(ctx, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, icp->nn_idx.alloc(ctx, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, icp->nn_d2.alloc(ctx, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, icp->sums.alloc(ctx, PCRS_ICP_NSUMS * sizeof(double)));
+    PCRS_HIP_CHECK(ctx, icp->state.alloc(ctx, sizeof(IcpLoopState)));
     return PCRS_OK;
 }
 
@@ -1070,9 +1068,9 @@ int pcrs_find_correspondences_dev(pcrs_index *target, const float *dsx, const fl
     if (n == 0) return PCRS_OK;
     if (!dsx || !dsy || !dsz) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
     DevBuf nn_idx, nn_d2, sums;
-    PCRS_HIP_CHECK(ctx, nn_idx.alloc(n * sizeof(uint32_t)));
-    PCRS_HIP_CHECK(ctx, nn_d2.alloc(n * sizeof(float)));
-    PCRS_HIP_CHECK(ctx, sums.alloc(PCRS_ICP_NSUMS * sizeof(double)));
+    PCRS_HIP_CHECK(ctx, nn_idx.alloc(ctx, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, nn_d2.alloc(ctx, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, sums.alloc(ctx, PCRS_ICP_NSUMS * sizeof(double)));
     PCRS_TRY(correspond_and_reduce(ctx, target, PCRS_ICP_POINT_TO_POINT, dsx, dsy, dsz, n, nullptr,
                                    nullptr, nullptr, max_distance, nn_idx.as<uint32_t>(),
                                    nn_d2.as<float>(), sums.as<double>(), dtgt_idx, ddist));
@@ -1096,8 +1094,8 @@ int pcrs_find_correspondences(pcrs_index *target, const float *sx, const float *
     PCRS_TRY(upload(ctx, dx, sx, n));
     PCRS_TRY(upload(ctx, dy, sy, n));
     PCRS_TRY(upload(ctx, dz, sz, n));
-    PCRS_HIP_CHECK(ctx, dti.alloc(n * sizeof(uint32_t)));
-    PCRS_HIP_CHECK(ctx, dd.alloc(n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, dti.alloc(ctx, n * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, dd.alloc(ctx, n * sizeof(float)));
     PCRS_TRY(pcrs_find_correspondences_dev(target, dx.as<float>(), dy.as<float>(), dz.as<float>(),
                                            n, max_distance, dti.as<uint32_t>(), dd.as<float>(),
                                            n_corr));

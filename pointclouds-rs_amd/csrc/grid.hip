@@ -1239,7 +1239,13 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     // a radius search wants cells of the radius (one attempt, no occupancy feedback)
     const bool fixed_cell = cell_request > 0.0f && cell_request < 1e30f;
     if (fixed_cell) cell = (double)cell_request;
-    const double max_cells = 4.0 * (double)nvalid + 4096.0;
+    // cell budget: 4 cells per point; experiments may override the factor
+    double cells_per_point = 4.0;
+    if (const char *e = getenv("PCRS_GRID_CELLS_PER_POINT")) {
+        const double v = atof(e);
+        if (v >= 1.0 && v <= 64.0) cells_per_point = v;
+    }
+    const double max_cells = cells_per_point * (double)nvalid + 4096.0;
     GridGeom g{};
     uint32_t ncell = 0;
     DevBuf counts, cell_id, table, table_sums, tmp, sorted;

@@ -1,0 +1,89 @@
+"""Randomised parity sweep: many small clouds of awkward shapes, random k, every consumer, all
+through the C-ABI against the oracle (bit-exact except normals, 1e-5)."""
+import numpy as np
+import pytest
+
+import gen
+
+F = np.float32
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pointclouds_rs import hip as h
+
+    return h
+
+
+def make_cloud(rng, kind, n):
+    if kind == "uniform":
+        p = rng.uniform(-10, 10, size=(n, 3))
+    elif kind == "clusters":
+        c = rng.uniform(-50, 50, size=(max(n // 40, 1), 3))
+        p = c[rng.integers(0, len(c), n)] + rng.normal(0, 0.05, size=(n, 3))
+    elif kind == "lattice":
+        p = rng.integers(0, 7, size=(n, 3)).astype(np.float64) * 0.5
+    elif kind == "plane":
+        p = np.concatenate([rng.uniform(-5, 5, size=(n, 2)), np.zeros((n, 1))], 1)
+    elif kind == "line":
+        p = np.concatenate([rng.uniform(-5, 5, size=(n, 1)), np.zeros((n, 2))], 1)
+    elif kind == "duplicates":
+        base = rng.uniform(-3, 3, size=(max(n // 10, 1), 3))
+        p = base[rng.integers(0, len(base), n)]
+    else:  # "wide": a dense core and a few points very far away
+        p = rng.normal(0, 1, size=(n, 3))
+        far = rng.integers(0, n, max(n // 50, 1))
+        p[far] *= 1e6
+    p = p.astype(F)
+    bad = rng.random(n) < 0.02
+    p[bad, rng.integers(0, 3, int(bad.sum()))] = rng.choice([np.nan, np.inf, -np.inf], int(bad.sum()))
+    return p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy()
+
+
+KINDS = ["uniform", "clusters", "lattice", "plane", "line", "duplicates", "wide"]
+
+
+@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("kind", KINDS)
+def test_random_clouds(hip, oracle, kind, seed):
+    rng = np.random.default_rng(1000 * KINDS.index(kind) + seed)
+    n = int(rng.choice([1, 2, 3, 17, 100, 1000, 5000, 9000]))
+    k = int(rng.choice([1, 2, 5, 10, 16, 17, 24, 33, 64, 70]))
+    x, y, z = make_cloud(rng, kind, n)
+    algo = 2 if n >= 64 else 0
+    # knn lists over the cloud itself and over a few outside queries
+    q = np.concatenate([np.stack([x, y, z], 1)[: min(n, 300)], rng.uniform(-60, 60, size=(20, 3)).astype(F)])
+    ix = hip.Index(x, y, z, k_hint=k, algo=algo)
+    idx, dist, cnt = ix.knn(q[:, 0], q[:, 1], q[:, 2], k)
+    ridx, rdist, _, rcnt = oracle.knn(x, y, z, q[:, 0], q[:, 1], q[:, 2], k, algo=0)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+    t, d, nc = ix.find_correspondences(q[:, 0], q[:, 1], q[:, 2], 5.0)
+    rt, rd, rnc = oracle.find_correspondences(q[:, 0], q[:, 1], q[:, 2], x, y, z, 5.0, algo=0)
+    assert nc == rnc and np.array_equal(t, rt) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+    ix.close()
+    # SOR and normals
+    ks = min(k, 40)
+    keep, n_keep, thr, mean = hip.sor(x, y, z, ks, 1.5)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, ks, 1.5, algo=0)
+    assert np.array_equal(mean.view(np.uint32), rmean.view(np.uint32))
+    assert np.array_equal(keep, rkeep) and n_keep == rn
+    assert (np.isnan(thr) and np.isnan(rthr)) or F(thr) == F(rthr)
+    if kind not in ("lattice", "line", "duplicates", "plane"):  # degenerate covariances: the
+        nrm = hip.normals(x, y, z, ks, (1.0, -2.0, 30.0))       # eigenvector is not unique there
+        rnrm = oracle.normals(x, y, z, ks, (1.0, -2.0, 30.0), algo=0)
+        for a, b in zip(nrm, rnrm):
+            assert np.abs(a.astype(np.float64) - b).max(initial=0.0) <= 1e-5
+    # the stages next to the path
+    r = float(rng.choice([0.05, 0.4, 2.0]))
+    _, _, count = hip.radius_outlier(x, y, z, r, 3)
+    _, _, rcount = oracle.radius_outlier(x, y, z, r, 3)
+    assert np.array_equal(count, rcount)
+    v = hip.voxel_downsample(x, y, z, r)
+    rv = oracle.voxel_downsample(x, y, z, r)
+    for a, b in zip(v, rv):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    cl = hip.euclidean_cluster(x, y, z, r, 2, 500)
+    rcl = oracle.euclidean_cluster(x, y, z, r, 2, 500)
+    assert len(cl) == len(rcl) and all(np.array_equal(a, b) for a, b in zip(cl, rcl))

@@ -337,7 +337,10 @@ struct CellArgs {
     //   qmode 1: position p is query p of (qx, qy, qz)
     //   qmode 2: query qlist[p] of (qx, qy, qz), p < *qcount
     //   qmode 3: sorted slot qlist[p], p < *qcount (self queries of a sub-range, compacted)
+    //   qmode 4: entry p of qpts (external queries sorted by grid cell: x, y, z, query index),
+    //            p < *qcount
     int qmode;
+    const float4 *qpts;
     const float *qx, *qy, *qz;
     uint32_t nq;
     uint32_t q_begin, q_len;
@@ -419,6 +422,12 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             const uint32_t orig = __float_as_uint(p.w);
             if (orig - a.q_begin >= a.q_len) continue;  // not a query of this call
             qi = orig - a.q_begin;
+            qx = p.x;
+            qy = p.y;
+            qz = p.z;
+        } else if (a.qmode == 4) {
+            const float4 p = a.qpts[pos];
+            qi = __float_as_uint(p.w);
             qx = p.x;
             qy = p.y;
             qz = p.z;
@@ -1192,6 +1201,32 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
 
 }  // namespace
 
+// The two-level sort of (x, y, z)[0..m) under plan sp: points by cell into `sorted` (x, y, z,
+// index), slot ranges into cell_start[0..ncell], occupied-cell count added to *d_nonempty.
+// table needs nb * nblk + 1 words (its last word receives the number of finite points),
+// table_sums the scan's block sums, tmp one float4 per finite point.
+static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
+                              uint32_t m, const SortPlan &sp, uint32_t *table, uint32_t *table_sums,
+                              float4 *tmp, float4 *sorted, uint32_t *cell_start,
+                              uint32_t *d_nonempty) {
+    const size_t entries = (size_t)sp.nb * sp.nblk;
+    hipLaunchKernelGGL(coarse_hist_kernel, dim3(sp.nblk), dim3(GB_THREADS), sp.nb * sizeof(uint32_t),
+                       ctx->stream, x, y, z, m, sp, table);
+    const uint32_t tblocks = (uint32_t)((entries + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    hipLaunchKernelGGL(scan_block_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream, table,
+                       (uint32_t)entries, table_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, table_sums, tblocks,
+                       table + entries);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream, table,
+                       (uint32_t)entries, table_sums);
+    hipLaunchKernelGGL(coarse_scatter_kernel, dim3(sp.nblk), dim3(GB_THREADS),
+                       sp.nb * sizeof(uint32_t), ctx->stream, x, y, z, m, sp, table, tmp);
+    hipLaunchKernelGGL(fine_sort_kernel, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp, sp,
+                       table, cell_start, sorted, d_nonempty);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
 int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     pcrs_ctx *ctx = ix->ctx;
     const uint32_t m = (uint32_t)ix->m;
@@ -1262,7 +1297,6 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         const bool two_level = plan_sort(g, ncell, m, &sp);
         if (two_level) {
             // the whole sort is cheaper than one pass of global atomics, so every attempt sorts
-            const size_t entries = (size_t)sp.nb * sp.nblk;
             if (!table.p) {
                 PCRS_HIP_CHECK(ctx, table.alloc(ctx, ((size_t)8192 * sp.nblk + 8) * sizeof(uint32_t)));
                 PCRS_HIP_CHECK(ctx, table_sums.alloc(
@@ -1271,22 +1305,9 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
                 PCRS_HIP_CHECK(ctx, sorted.alloc(ctx, nvalid * sizeof(float4)));
             }
             PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_nonempty, 0, sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(coarse_hist_kernel, dim3(sp.nblk), dim3(GB_THREADS),
-                               sp.nb * sizeof(uint32_t), ctx->stream, ix->x, ix->y, ix->z, m, sp,
-                               table.as<uint32_t>());
-            const uint32_t tblocks = (uint32_t)((entries + SCAN_BLOCK - 1) / SCAN_BLOCK);
-            hipLaunchKernelGGL(scan_block_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream,
-                               table.as<uint32_t>(), (uint32_t)entries, table_sums.as<uint32_t>());
-            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                               table_sums.as<uint32_t>(), tblocks, table.as<uint32_t>() + entries);
-            hipLaunchKernelGGL(scan_add_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream,
-                               table.as<uint32_t>(), (uint32_t)entries, table_sums.as<uint32_t>());
-            hipLaunchKernelGGL(coarse_scatter_kernel, dim3(sp.nblk), dim3(GB_THREADS),
-                               sp.nb * sizeof(uint32_t), ctx->stream, ix->x, ix->y, ix->z, m, sp,
-                               table.as<uint32_t>(), tmp.as<float4>());
-            hipLaunchKernelGGL(fine_sort_kernel, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream,
-                               tmp.as<float4>(), sp, table.as<uint32_t>(), counts.as<uint32_t>(),
-                               sorted.as<float4>(), d_nonempty);
+            PCRS_TRY(run_two_level_sort(ctx, ix->x, ix->y, ix->z, m, sp, table.as<uint32_t>(),
+                                        table_sums.as<uint32_t>(), tmp.as<float4>(),
+                                        sorted.as<float4>(), counts.as<uint32_t>(), d_nonempty));
         } else {
             if (!cell_id.p) PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
             PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
@@ -1514,7 +1535,8 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.fail_list = listA;
     a.fail_count = &counters[0];
     unsigned blocks1 = (unsigned)((nq + GB_THREADS - 1) / GB_THREADS);
-    DevBuf own_counts, own_sums;
+    DevBuf own_counts, own_sums, q_table, q_sums, q_tmp, q_sorted, q_cells;
+    bool sorted_queries = false;
     if (q.self && !nn_only) {
         a.q_begin = (uint32_t)q.out_offset;
         a.q_len = nq;
@@ -1542,6 +1564,27 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     } else {
         a.qmode = 1;
         a.nq = nq;
+        // A large batch of explicit queries arrives in the caller's order: neighbouring lanes
+        // would walk unrelated cells.  Sorting the queries by the cell they fall into (the same
+        // two-level sort as the index build, under the index's own geometry) restores that.
+        SortPlan sp{};
+        if (!nn_only && nq >= 32768 && plan_sort(ix->g, ix->ncell, nq, &sp)) {
+            PCRS_HIP_CHECK(ctx, q_table.alloc(ctx, ((size_t)sp.nb * sp.nblk + 8) * sizeof(uint32_t)));
+            PCRS_HIP_CHECK(ctx, q_sums.alloc(ctx, (((size_t)sp.nb * sp.nblk) / SCAN_BLOCK + 2) *
+                                                      sizeof(uint32_t)));
+            PCRS_HIP_CHECK(ctx, q_tmp.alloc(ctx, (size_t)nq * sizeof(float4)));
+            PCRS_HIP_CHECK(ctx, q_sorted.alloc(ctx, (size_t)nq * sizeof(float4)));
+            PCRS_HIP_CHECK(ctx, q_cells.alloc(ctx, ((size_t)ix->ncell + 8) * sizeof(uint32_t)));
+            uint32_t *q_nonempty = q_cells.as<uint32_t>() + ix->ncell + 1;
+            PCRS_HIP_CHECK(ctx, hipMemsetAsync(q_nonempty, 0, sizeof(uint32_t), ctx->stream));
+            PCRS_TRY(run_two_level_sort(ctx, q.qx, q.qy, q.qz, nq, sp, q_table.as<uint32_t>(),
+                                        q_sums.as<uint32_t>(), q_tmp.as<float4>(),
+                                        q_sorted.as<float4>(), q_cells.as<uint32_t>(), q_nonempty));
+            a.qmode = 4;
+            a.qpts = q_sorted.as<float4>();
+            a.qcount = q_table.as<uint32_t>() + (size_t)sp.nb * sp.nblk;  // finite queries
+            sorted_queries = true;
+        }
     }
     // normals: the search kernels leave covariance sums, a light kernel solves them afterwards
     DevBuf cov;
@@ -1611,7 +1654,8 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     }
     ctx->timing = timing_was;
     PCRS_TRY(rc_bf);
-    // self queries answered from the sorted array never saw the non-finite points of the range
+    // queries answered from a sorted array never saw the non-finite ones among them
+    if (sorted_queries) PCRS_TRY(pcrs_launch_invalid_defaults(ctx, ix->x, ix->y, ix->z, q, out_in));
     if (q.self && !nn_only && ix->nvalid < ix->m)
         PCRS_TRY(pcrs_launch_invalid_defaults(ctx, ix->x, ix->y, ix->z, q, out_in));  // no cov
     ix->stats_dev = counters;

@@ -120,6 +120,13 @@ def load_library():
                 f"{LIB_PATH} is missing: build it with `make -C pointclouds-rs_amd/csrc` "
                 "(there is no CPU fallback)"
             )
+        # PyTorch-ROCm ships its own copy of the HIP runtime.  When both end up in one process the
+        # copy loaded second finds no GPU, so torch (when installed) goes first and the library
+        # then binds to the runtime that is already there.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

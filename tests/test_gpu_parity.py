@@ -344,6 +344,23 @@ def test_correspondences_and_step_sums(hip, oracle, algo):
     icp.close()
 
 
+def test_knn_large_external_batch(hip, oracle):
+    """Batches of 32768+ explicit queries are sorted by grid cell inside the library; results
+    must still come back in the caller's order, defaults for non-finite queries included."""
+    x, y, z = gen.uniform_cloud(50000, 12, 0, 30)
+    rng = np.random.default_rng(4)
+    q = rng.uniform(-5, 35, size=(40000, 3)).astype(F)
+    q[::997, 1] = np.nan
+    q[5::1999, 2] = np.inf
+    for k in (1, 7):
+        ix = hip.Index(x, y, z, k_hint=k, algo=2)
+        idx, dist, cnt = ix.knn(q[:, 0], q[:, 1], q[:, 2], k)
+        ix.close()
+        ridx, rdist, _, rcnt = oracle.knn(x, y, z, q[:, 0], q[:, 1], q[:, 2], k, algo=1)
+        assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
+        assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+
+
 def test_correspondences_far_and_crowded_queries(hip, oracle):
     """1-NN queries that leave the 27-cell cube: far outside the cloud (escalating radii up to
     the whole grid), inside a crowded cell (handed to the wave kernel), non-finite."""

@@ -997,12 +997,13 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
                           const float *tny, const float *tnz, float max_d, uint32_t *nn_idx,
                           float *nn_d2, double *dsums, uint32_t *tgt_out, float *dist_out,
                           IcpLoopState *d_state = nullptr, size_t n_source = 0,
-                          float tolerance = 0.0f) {
+                          float tolerance = 0.0f, bool coherent = false) {
     KnnQuery q;
     q.qx = cx;
     q.qy = cy;
     q.qz = cz;
     q.nq = n;
+    q.coherent = coherent;
     KnnOut o;
     o.nn_idx = nn_idx;
     o.nn_d2 = nn_d2;
@@ -1221,7 +1222,8 @@ int pcrs_icp_accumulate(pcrs_icp *icp, int mode, float max_distance, double *sum
                                    icp->cur[1].as<float>(), icp->cur[2].as<float>(), icp->n,
                                    icp->tnx, icp->tny, icp->tnz, max_distance,
                                    icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
-                                   icp->sums.as<double>(), nullptr, nullptr));
+                                   icp->sums.as<double>(), nullptr, nullptr, nullptr, 0, 0.0f,
+                                   icp->perm.p != nullptr));
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, PCRS_ICP_NSUMS * sizeof(double), &pin));
     PCRS_TRY(download(ctx, pin, icp->sums.p, PCRS_ICP_NSUMS * sizeof(double)));
@@ -1325,7 +1327,8 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
                                            icp->tny, icp->tnz, max_correspondence_distance,
                                            icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
                                            icp->sums.as<double>(), nullptr, nullptr, ds, icp->n,
-                                           tolerance));  // the reduction's last kernel runs the tail
+                                           tolerance, icp->perm.p != nullptr));  // the last kernel of
+                                                                                  // the reduction runs the tail
             PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));  // icp.rs:186
         }
         iter += nb;

@@ -899,7 +899,7 @@ constexpr int NN_SUB = 8;
 
 __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut out) {
     uint32_t total = a.nq;
-    if (a.qmode == 2) total = *a.qcount;
+    if (a.qmode == 2 || a.qmode == 4) total = *a.qcount;
     const GridGeom &g = a.g;
     const uint32_t sub = threadIdx.x & (NN_SUB - 1);
     const uint32_t groups_per_grid = gridDim.x * (GB_THREADS / NN_SUB);
@@ -908,9 +908,16 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
          q0 += groups_per_grid) {
         const uint32_t qpos = q0 + ((threadIdx.x & 63u) / NN_SUB);
         const bool active = qpos < total;
-        const uint32_t qi = active ? ((a.qmode == 2) ? a.qlist[qpos] : qpos) : 0u;
+        uint32_t qi = 0u;
         float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-        if (active) {
+        if (active && a.qmode == 4) {  // queries sorted by cell: (x, y, z, query index)
+            const float4 p = a.qpts[qpos];
+            qi = __float_as_uint(p.w);
+            qx = p.x;
+            qy = p.y;
+            qz = p.z;
+        } else if (active) {
+            qi = (a.qmode == 2) ? a.qlist[qpos] : qpos;
             qx = a.qx[qi];
             qy = a.qy[qi];
             qz = a.qz[qi];
@@ -1568,7 +1575,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         // would walk unrelated cells.  Sorting the queries by the cell they fall into (the same
         // two-level sort as the index build, under the index's own geometry) restores that.
         SortPlan sp{};
-        if (!nn_only && nq >= 32768 && plan_sort(ix->g, ix->ncell, nq, &sp)) {
+        if (!q.coherent && nq >= 32768 && plan_sort(ix->g, ix->ncell, nq, &sp)) {
             PCRS_HIP_CHECK(ctx, q_table.alloc(ctx, ((size_t)sp.nb * sp.nblk + 8) * sizeof(uint32_t)));
             PCRS_HIP_CHECK(ctx, q_sums.alloc(ctx, (((size_t)sp.nb * sp.nblk) / SCAN_BLOCK + 2) *
                                                       sizeof(uint32_t)));

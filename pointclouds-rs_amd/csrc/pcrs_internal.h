@@ -168,6 +168,7 @@ struct KnnQuery {
     size_t nq = 0;
     size_t out_offset = 0;  // self queries: first query is point out_offset of the cloud
     bool self = false;
+    bool coherent = false;  // explicit queries already in a spatial order: do not sort them again
 };
 
 // ---- brute force (knn_bf.hip)

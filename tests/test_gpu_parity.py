@@ -359,6 +359,11 @@ def test_knn_large_external_batch(hip, oracle):
         ridx, rdist, _, rcnt = oracle.knn(x, y, z, q[:, 0], q[:, 1], q[:, 2], k, algo=1)
         assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
         assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+    ix = hip.Index(x, y, z, k_hint=1, algo=2)
+    t, d, n = ix.find_correspondences(q[:, 0], q[:, 1], q[:, 2], 2.0)
+    ix.close()
+    rt, rd, rn = oracle.find_correspondences(q[:, 0], q[:, 1], q[:, 2], x, y, z, 2.0, algo=1)
+    assert n == rn and np.array_equal(t, rt) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))
 
 
 def test_correspondences_far_and_crowded_queries(hip, oracle):

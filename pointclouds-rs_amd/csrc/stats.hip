@@ -89,59 +89,127 @@ __global__ __launch_bounds__(256) void chunk_sums_kernel(const float *mean, size
 }
 
 // exclusive f64 scan of the chunk sums (in place) and the total finite count
-__global__ __launch_bounds__(1024) void chunk_scan_kernel(double *csum, const uint32_t *ccnt,
-                                                          const float *cmax, uint32_t nchunks,
-                                                          StatsScalars *sc, int write_count) {
+// Exclusive f64 prefix of the chunk sums, the count of finite elements and the largest element,
+// in two launches: every block scans one stretch of 4096 chunks in place and leaves the stretch's
+// totals; the second launch adds the totals of the stretches before it.  A cloud of one stretch
+// is finished by the first launch.
+constexpr uint32_t ST_SCAN_SPAN = 4096;
+
+__global__ __launch_bounds__(1024) void chunk_scan_local_kernel(
+    double *csum, const uint32_t *ccnt, const float *cmax, uint32_t nchunks, double *ssum,
+    unsigned long long *scnt, float *smax, StatsScalars *sc, int write_count) {
     __shared__ double wsum[16];
     __shared__ unsigned long long wcnt[16];
     __shared__ float wmax[16];
+    const uint32_t b = blockIdx.x * ST_SCAN_SPAN + threadIdx.x * 4u;
+    double v[4];
+    double s = 0.0;
+    unsigned long long c = 0;
     float mx = 0.0f;
-    for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) mx = fmaxf(mx, cmax[i]);
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) mx = fmaxf(mx, wmax[w]);
-        sc->max_bits = __float_as_uint(mx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool in = b + j < nchunks;
+        v[j] = in ? csum[b + j] : 0.0;
+        s += v[j];
+        c += in ? ccnt[b + j] : 0u;
+        mx = fmaxf(mx, in ? cmax[b + j] : 0.0f);
     }
-    __shared__ double carry_s;
-    __shared__ unsigned long long carry_c;
-    if (threadIdx.x == 0) {
-        carry_s = 0.0;
-        carry_c = 0;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < nchunks; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const double v = (i < nchunks) ? csum[i] : 0.0;
-        unsigned long long c = (i < nchunks) ? ccnt[i] : 0;
-        double incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const double o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
+    double incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        c += __shfl_down(c, off, 64);
+        mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    }
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) {
+        wcnt[wave] = c;
+        wmax[wave] = mx;
+    }
+    __syncthreads();
+    double run = incl - s;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (b + j < nchunks) csum[b + j] = run;
+        run += v[j];
+    }
+    if (threadIdx.x == 0) {
+        double total_s = 0.0;
+        unsigned long long total = 0;
+        float m = 0.0f;
+        for (int w = 0; w < 16; ++w) {
+            total_s += wsum[w];
+            total += wcnt[w];
+            m = fmaxf(m, wmax[w]);
         }
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-        if (lane == 63) wsum[wave] = incl;
-        if (lane == 0) wcnt[wave] = c;
-        __syncthreads();
-        double wave_off = 0.0;
-        for (int w = 0; w < wave; ++w) wave_off += wsum[w];
-        const double carry = carry_s;
-        if (i < nchunks) csum[i] = carry + wave_off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+        if (gridDim.x == 1) {
+            sc->max_bits = __float_as_uint(m);
+            if (write_count) {
+                sc->nf = total;
+                sc->has_finite = total ? 1u : 0u;
+            }
+        } else {
+            ssum[blockIdx.x] = total_s;
+            scnt[blockIdx.x] = total;
+            smax[blockIdx.x] = m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void chunk_scan_base_kernel(
+    double *csum, uint32_t nchunks, const double *ssum, const unsigned long long *scnt,
+    const float *smax, StatsScalars *sc, int write_count) {
+    __shared__ double wsum[16];
+    __shared__ unsigned long long wcnt[16];
+    __shared__ float wmax[16];
+    // stretch totals before this block (block 0: all of them, for the count and the maximum)
+    const uint32_t upto = blockIdx.x == 0 ? gridDim.x : blockIdx.x;
+    double s = 0.0;
+    unsigned long long c = 0;
+    float mx = 0.0f;
+    for (uint32_t i = threadIdx.x; i < upto; i += 1024u) {
+        s += ssum[i];
+        c += scnt[i];
+        mx = fmaxf(mx, smax[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        c += __shfl_down(c, off, 64);
+        mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        wsum[wave] = s;
+        wcnt[wave] = c;
+        wmax[wave] = mx;
+    }
+    __syncthreads();
+    double base = 0.0;
+    unsigned long long total = 0;
+    float m = 0.0f;
+    for (int w = 0; w < 16; ++w) {
+        base += wsum[w];
+        total += wcnt[w];
+        m = fmaxf(m, wmax[w]);
+    }
+    if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
-            unsigned long long t = carry_c;
-            for (int w = 0; w < 16; ++w) t += wcnt[w];
-            carry_c = t;
+            sc->max_bits = __float_as_uint(m);
+            if (write_count) {
+                sc->nf = total;
+                sc->has_finite = total ? 1u : 0u;
+            }
         }
-        __syncthreads();
+        return;
     }
-    if (threadIdx.x == 0 && write_count) {
-        sc->nf = carry_c;
-        sc->has_finite = carry_c ? 1u : 0u;
-    }
+    const uint32_t b = blockIdx.x * ST_SCAN_SPAN + threadIdx.x * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (b + j < nchunks) csum[b + j] += base;
 }
 
 __device__ __forceinline__ Composite compose(const Composite &f, const Composite &g) {
@@ -273,25 +341,48 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
     // walks the chunks [chunk_begin, nchunks); the state crosses launches in sc->run
     constexpr int G = 4;
     constexpr uint32_t BATCH = 64u * G;
+    static_assert(ST_PER_LANE == 4, "the element-wise path moves one float4 per lane");
+    __shared__ float4 elems[64];
     const int lane = threadIdx.x;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
     float s = chunk_begin ? sc->run : 0.0f;  // uniform across the wave
 #ifdef PCRS_STATS_DEBUG
-    uint32_t dbg_fallbacks = 0;
+    uint32_t dbg_fallbacks = 0, dbg_rounds = 0;
+    long long dbg_t_fb = 0, dbg_t0 = wall_clock64();
 #endif
-    for (uint32_t base = chunk_begin; base < nchunks; base += BATCH) {
-        Composite mine[G][W];
+    // the composites of the next batch are requested while the current one is being scanned
+    auto load_batch = [&](uint32_t base, Composite (&dst)[G][W]) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             const uint32_t ci = base + (uint32_t)lane * G + k;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                mine[k][j].a0 = mine[k][j].a1 = 0;
-                mine[k][j].e = ST_NO_BINADE;
-                mine[k][j].pad = 0;
-                if (ci < nchunks) mine[k][j] = comp[(size_t)ci * W + j];
+                dst[k][j].a0 = dst[k][j].a1 = 0;
+                dst[k][j].e = ST_NO_BINADE;
+                dst[k][j].pad = 0;
+                if (ci < nchunks) dst[k][j] = comp[(size_t)ci * W + j];
             }
         }
+    };
+    auto load_elements = [&](uint32_t chunk) {  // this lane's four elements of a chunk
+        bool fin;
+        const size_t e0 = (size_t)chunk * ST_CHUNK + lane * ST_PER_LANE;
+        float4 v;
+        v.x = stat_element<PASS>(mean, n, e0 + 0, mu, &fin);
+        v.y = stat_element<PASS>(mean, n, e0 + 1, mu, &fin);
+        v.z = stat_element<PASS>(mean, n, e0 + 2, mu, &fin);
+        v.w = stat_element<PASS>(mean, n, e0 + 3, mu, &fin);
+        return v;
+    };
+    Composite ahead[G][W];
+    load_batch(chunk_begin, ahead);
+    for (uint32_t base = chunk_begin; base < nchunks; base += BATCH) {
+        Composite mine[G][W];
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+#pragma unroll
+            for (int j = 0; j < W; ++j) mine[k][j] = ahead[k][j];
+        if (base + BATCH < nchunks) load_batch(base + BATCH, ahead);
         const uint32_t lim = min(BATCH, nchunks - base);
         uint32_t pos = 0;
         while (pos < lim) {
@@ -320,21 +411,30 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                 }
                 p[k] = (k == 0) ? u : compose(p[k - 1], u);
             }
+            // inclusive scan over the lanes with data-parallel-primitive moves: lanes a move does
+            // not reach receive {0, 0}, the identity of the composition
             Composite f = p[G - 1];
-            for (int off = 1; off < 64; off <<= 1) {
-                Composite g;
-                g.a0 = __shfl_up(f.a0, off, 64);
-                g.a1 = __shfl_up(f.a1, off, 64);
-                g.e = e_now;
-                g.pad = 0;
-                if (lane >= off) f = compose(g, f);
-            }
-            Composite ex;  // everything before this lane's chunks
-            ex.a0 = __shfl_up(f.a0, 1, 64);
-            ex.a1 = __shfl_up(f.a1, 1, 64);
+#define PCRS_SCAN_STEP(CTRL, ROWS)                                                          \
+    {                                                                                       \
+        Composite g;                                                                        \
+        g.a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.a0, CTRL, ROWS, 0xf, false); \
+        g.a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.a1, CTRL, ROWS, 0xf, false); \
+        g.e = e_now;                                                                        \
+        g.pad = 0;                                                                          \
+        f = compose(g, f);                                                                  \
+    }
+            PCRS_SCAN_STEP(0x111, 0xf)  // row_shr:1
+            PCRS_SCAN_STEP(0x112, 0xf)  // row_shr:2
+            PCRS_SCAN_STEP(0x114, 0xf)  // row_shr:4
+            PCRS_SCAN_STEP(0x118, 0xf)  // row_shr:8
+            PCRS_SCAN_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+            PCRS_SCAN_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef PCRS_SCAN_STEP
+            Composite ex;  // everything before this lane's chunks (wave_shr:1)
+            ex.a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.a0, 0x138, 0xf, 0xf, false);
+            ex.a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.a1, 0x138, 0xf, 0xf, false);
             ex.e = e_now;
             ex.pad = 0;
-            if (lane == 0) ex.a0 = ex.a1 = 0;
             uint32_t S_after[G];
             int first_k = G;  // first of this lane's chunks whose state left the binade
 #pragma unroll
@@ -361,7 +461,8 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
             if (first_bad < lim) {
 #ifdef PCRS_STATS_DEBUG
                 ++dbg_fallbacks;
-                if (lane == 0 && dbg_fallbacks <= 40)
+                const long long dbg_f0 = wall_clock64();
+                if (lane == 0 && dbg_fallbacks <= 0)
                     printf("pass %d fallback %u: chunk %u e_now %d built for %d %d %d %d\n", PASS,
                            dbg_fallbacks, base + first_bad, e_now,
                            comp[(size_t)(base + first_bad) * W].e,
@@ -370,28 +471,35 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                            W > 3 ? comp[(size_t)(base + first_bad) * W + 3].e : 0);
 #endif
                 // element-by-element f32 adds over this chunk (lane-major element order)
-                float v[ST_PER_LANE];
-#pragma unroll
-                for (int k = 0; k < ST_PER_LANE; ++k) {
-                    bool fin;
-                    v[k] = stat_element<PASS>(
-                        mean, n, (size_t)(base + first_bad) * ST_CHUNK + lane * ST_PER_LANE + k, mu,
-                        &fin);
-                }
+                const uint32_t bad_chunk = base + first_bad;
+                const float4 mine4 = load_elements(bad_chunk);
+                // through shared memory: every lane reads all 256 values back (broadcast reads)
+                // and runs the same chain of adds
+                elems[lane] = mine4;
+                __builtin_amdgcn_wave_barrier();  // one wave: its LDS accesses complete in order
+#pragma unroll 16
                 for (int l = 0; l < 64; ++l) {
-#pragma unroll
-                    for (int k = 0; k < ST_PER_LANE; ++k) {
-                        const float x = __uint_as_float(
-                            __builtin_amdgcn_readlane(__float_as_uint(v[k]), l));
-                        s = s + x;
-                    }
+                    const float4 x = elems[l];
+                    s = s + x.x;
+                    s = s + x.y;
+                    s = s + x.z;
+                    s = s + x.w;
                 }
+                __builtin_amdgcn_wave_barrier();
+#ifdef PCRS_STATS_DEBUG
+                dbg_t_fb += wall_clock64() - dbg_f0;
+#endif
             }
+#ifdef PCRS_STATS_DEBUG
+            ++dbg_rounds;
+#endif
             pos = first_bad + 1;
         }
     }
 #ifdef PCRS_STATS_DEBUG
-    if (lane == 0) printf("pass %d: %u element-wise chunks of %u, final s %g\n", PASS, dbg_fallbacks, nchunks, s);
+    if (lane == 0)
+        printf("pass %d: %u element-wise chunks of %u, %u rounds, final s %g; ticks total %lld fallback %lld\n",
+               PASS, dbg_fallbacks, nchunks, dbg_rounds, s, wall_clock64() - dbg_t0, dbg_t_fb);
 #endif
     if (lane == 0) sc->run = s;
     if (lane == 0 && last) {
@@ -492,16 +600,29 @@ int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std
     char *after = w + (size_t)nchunks * (sizeof(double) + (size_t)W * sizeof(Composite));
     uint32_t *ccnt = reinterpret_cast<uint32_t *>(after);
     float *cmax = reinterpret_cast<float *>(after + (size_t)nchunks * sizeof(uint32_t));
+    const uint32_t nspans = (nchunks + ST_SCAN_SPAN - 1) / ST_SCAN_SPAN;
+    uintptr_t sp = reinterpret_cast<uintptr_t>(cmax + nchunks);
+    sp = (sp + 7u) & ~(uintptr_t)7u;
+    double *ssum = reinterpret_cast<double *>(sp);
+    unsigned long long *scnt = reinterpret_cast<unsigned long long *>(ssum + nspans);
+    float *smax = reinterpret_cast<float *>(scnt + nspans);
+    auto scan = [&](int write_count) {
+        hipLaunchKernelGGL(chunk_scan_local_kernel, dim3(nspans), dim3(1024), 0, ctx->stream, csum,
+                           ccnt, cmax, nchunks, ssum, scnt, smax, sc, write_count);
+        if (nspans > 1)
+            hipLaunchKernelGGL(chunk_scan_base_kernel, dim3(nspans), dim3(1024), 0, ctx->stream,
+                               csum, nchunks, ssum, scnt, smax, sc, write_count);
+    };
     PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
     if (n == 0) return PCRS_OK;
     const dim3 cgrid((nchunks + 3) / 4), cblock(256);
     // pass 1: mean
     hipLaunchKernelGGL(chunk_sums_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, cmax, nchunks, sc, 1);
+    scan(1);
     run_pass<1>(ctx, W, dmean, n, sc, csum, comp, nchunks, std_mul);
     // pass 2: variance
     hipLaunchKernelGGL(chunk_sums_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, csum, ccnt, cmax, nchunks, sc, 0);
+    scan(0);
     run_pass<2>(ctx, W, dmean, n, sc, csum, comp, nchunks, std_mul);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
@@ -514,7 +635,9 @@ static int stats_window(size_t n) { return n > (size_t)4 << 20 ? 4 : 1; }
 size_t pcrs_sor_stats_workspace(size_t n) {
     const size_t nchunks = (n + ST_CHUNK - 1) / ST_CHUNK + 1;
     return nchunks * (sizeof(double) + (size_t)stats_window(n) * sizeof(Composite) +
-                      sizeof(uint32_t) + sizeof(float)) + 64;
+                      sizeof(uint32_t) + sizeof(float)) +
+           (nchunks / ST_SCAN_SPAN + 2) * (sizeof(double) + sizeof(unsigned long long) + sizeof(float)) +
+           128;
 }
 
 size_t pcrs_sor_stats_scalars_bytes() { return sizeof(StatsScalars); }

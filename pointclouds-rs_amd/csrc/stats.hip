@@ -326,6 +326,69 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
     }
 }
 
+// Composite of a whole batch of 256 chunks (the unit of the walker's scan), for the binades of
+// the batch's first chunk: where the running sum stays in its binade over all 65536 elements —
+// nearly everywhere — the walker applies this one function and never looks at the chunks.
+// One wave per batch; lane l folds the chunks 4l .. 4l+3, an ordered tree folds the lanes.
+template <int W>
+__global__ __launch_bounds__(64) void batch_composite_kernel(const Composite *comp,
+                                                             Composite *bcomp,
+                                                             uint32_t chunk_begin,
+                                                             uint32_t chunk_end) {
+    constexpr int G = 4;
+    const int lane = threadIdx.x;
+    const uint32_t base = chunk_begin + blockIdx.x * (64u * G);
+    if (base >= chunk_end) return;
+    Composite mine[G][W];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const uint32_t ci = base + (uint32_t)lane * G + k;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            mine[k][j].a0 = mine[k][j].a1 = 0;
+            mine[k][j].e = ST_NO_BINADE;
+            mine[k][j].pad = 0;
+            if (ci < chunk_end) mine[k][j] = comp[(size_t)ci * W + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int ej = __builtin_amdgcn_readfirstlane(mine[0][j].e);
+        Composite f;
+        f.a0 = f.a1 = 0;
+        f.e = ej;
+        f.pad = 0;
+        if (ej != ST_NO_BINADE) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const uint32_t ci = base + (uint32_t)lane * G + k;
+                Composite u;
+                u.e = ej;
+                u.pad = 0;
+                u.a0 = u.a1 = ci < chunk_end ? ST_SAT : 0u;  // past the end: identity
+                if (ci < chunk_end) {
+#pragma unroll
+                    for (int q = 0; q < W; ++q)
+                        if (mine[k][q].e == ej) {
+                            u.a0 = mine[k][q].a0;
+                            u.a1 = mine[k][q].a1;
+                        }
+                }
+                f = compose(f, u);
+            }
+            for (int off = 1; off < 64; off <<= 1) {
+                Composite g;
+                g.a0 = __shfl_down(f.a0, off, 64);
+                g.a1 = __shfl_down(f.a1, off, 64);
+                g.e = ej;
+                g.pad = 0;
+                if ((lane & (2 * off - 1)) == 0) f = compose(f, g);
+            }
+        }
+        if (lane == 0) bcomp[(size_t)(base / (64u * G)) * W + j] = f;
+    }
+}
+
 // One wave walks the chunks in order carrying the exact f32 running sum.  256 chunk composites
 // are taken at a time, four consecutive ones per lane: each lane composes its own four, an
 // inclusive scan of function composition over the lanes then gives the state after every chunk
@@ -336,6 +399,7 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
 template <int PASS, int W>
 __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_t n,
                                                         StatsScalars *sc, const Composite *comp,
+                                                        const Composite *bcomp,
                                                         uint32_t chunk_begin, uint32_t nchunks,
                                                         bool last, float std_mul) {
     // walks the chunks [chunk_begin, nchunks); the state crosses launches in sc->run
@@ -347,7 +411,7 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
     float s = chunk_begin ? sc->run : 0.0f;  // uniform across the wave
 #ifdef PCRS_STATS_DEBUG
-    uint32_t dbg_fallbacks = 0, dbg_rounds = 0;
+    uint32_t dbg_fallbacks = 0, dbg_rounds = 0, dbg_whole = 0;
     long long dbg_t_fb = 0, dbg_t0 = wall_clock64();
 #endif
     // the composites of the next batch are requested while the current one is being scanned
@@ -374,15 +438,61 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
         v.w = stat_element<PASS>(mean, n, e0 + 3, mu, &fin);
         return v;
     };
-    Composite ahead[G][W];
-    load_batch(chunk_begin, ahead);
+    // The batch composites of the whole section are requested up front, batch 64 t + l in lane l
+    // (a section has at most 64 * BPL batches; further ones are walked chunk by chunk); the chunk
+    // composites are only loaded where a batch cannot be taken whole.
+    constexpr int BPL = 2;
+    Composite whole_of[BPL][W];
+#pragma unroll
+    for (int t = 0; t < BPL; ++t) {
+        const uint32_t bbase = chunk_begin + (uint32_t)(t * 64 + lane) * BATCH;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            whole_of[t][j].a0 = whole_of[t][j].a1 = ST_SAT;
+            whole_of[t][j].e = ST_NO_BINADE;
+            whole_of[t][j].pad = 0;
+            if (bbase < nchunks) whole_of[t][j] = bcomp[(size_t)(bbase / BATCH) * W + j];
+        }
+    }
     for (uint32_t base = chunk_begin; base < nchunks; base += BATCH) {
+        const uint32_t bi = (base - chunk_begin) / BATCH;  // uniform
+        Composite whole[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            whole[j].a0 = whole[j].a1 = ST_SAT;
+            whole[j].e = ST_NO_BINADE;
+        }
+#pragma unroll
+        for (int t = 0; t < BPL; ++t)
+            if ((int)(bi >> 6) == t) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const int src = (int)(bi & 63u);
+                    whole[j].a0 = __builtin_amdgcn_readlane(whole_of[t][j].a0, src);
+                    whole[j].a1 = __builtin_amdgcn_readlane(whole_of[t][j].a1, src);
+                    whole[j].e = __builtin_amdgcn_readlane(whole_of[t][j].e, src);
+                }
+            }
+        {
+            const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+            const int e_now = binade_of(__uint_as_float(bits));
+            const uint32_t S = (bits & 0x7FFFFFu) | 0x800000u;
+            uint32_t inc = ST_SAT;
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                if (e_now != ST_NO_BINADE && whole[j].e == e_now)
+                    inc = (S & 1u) ? whole[j].a1 : whole[j].a0;
+            // the sum only grows: in the binade after the batch = in the binade throughout
+            if (inc < ST_SAT && S + inc < (1u << 24)) {
+                s = __uint_as_float((bits & 0xFF800000u) | ((S + inc) & 0x7FFFFFu));
+#ifdef PCRS_STATS_DEBUG
+                ++dbg_whole;
+#endif
+                continue;
+            }
+        }
         Composite mine[G][W];
-#pragma unroll
-        for (int k = 0; k < G; ++k)
-#pragma unroll
-            for (int j = 0; j < W; ++j) mine[k][j] = ahead[k][j];
-        if (base + BATCH < nchunks) load_batch(base + BATCH, ahead);
+        load_batch(base, mine);
         const uint32_t lim = min(BATCH, nchunks - base);
         uint32_t pos = 0;
         while (pos < lim) {
@@ -498,8 +608,8 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
     }
 #ifdef PCRS_STATS_DEBUG
     if (lane == 0)
-        printf("pass %d: %u element-wise chunks of %u, %u rounds, final s %g; ticks total %lld fallback %lld\n",
-               PASS, dbg_fallbacks, nchunks, dbg_rounds, s, wall_clock64() - dbg_t0, dbg_t_fb);
+        printf("pass %d: %u element-wise chunks of %u, %u rounds, %u whole batches, final s %g; ticks total %lld fallback %lld\n",
+               PASS, dbg_fallbacks, nchunks, dbg_rounds, dbg_whole, s, wall_clock64() - dbg_t0, dbg_t_fb);
 #endif
     if (lane == 0) sc->run = s;
     if (lane == 0 && last) {
@@ -567,21 +677,32 @@ static int stats_window(size_t n);
 // is known (everything is queued on the stream; nothing comes back to the host).
 template <int PASS>
 static void run_pass(pcrs_ctx *ctx, int W, const float *dmean, size_t n, StatsScalars *sc,
-                     const double *csum, Composite *comp, uint32_t nchunks, float std_mul) {
+                     const double *csum, Composite *comp, Composite *bcomp, uint32_t nchunks,
+                     float std_mul) {
+    constexpr uint32_t kBatch = 256;  // chunks per batch composite = per scan of the walker
     if (W == 1) {
         hipLaunchKernelGGL((chunk_composite_kernel<PASS, 1>), dim3((nchunks + 3) / 4), dim3(256), 0,
                            ctx->stream, dmean, n, sc, csum, comp, 0u, nchunks);
+        hipLaunchKernelGGL((batch_composite_kernel<1>), dim3((nchunks + kBatch - 1) / kBatch),
+                           dim3(64), 0, ctx->stream, comp, bcomp, 0u, nchunks);
         hipLaunchKernelGGL((stats_walk_kernel<PASS, 1>), dim3(1), dim3(64), 0, ctx->stream, dmean, n,
-                           sc, comp, 0u, nchunks, true, std_mul);
+                           sc, comp, bcomp, 0u, nchunks, true, std_mul);
         return;
     }
-    constexpr uint32_t kSection = 4096;
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += kSection) {
-        const uint32_t c1 = c0 + kSection < nchunks ? c0 + kSection : nchunks;
+    // Before element i the f32 sum s and the exact prefix p obey p / (1 + i 2^-24) <= s <=
+    // p / (1 - i 2^-24) (every add is off by at most half an ulp of s), so over the first 2^23
+    // elements s stays within one binade of p and needs no anchor: one long first section.
+    constexpr uint32_t kSection = 4096, kFirst = (1u << 23) / ST_CHUNK;
+    static_assert(kSection % kBatch == 0 && kFirst % kBatch == 0, "sections start on a batch");
+    for (uint32_t c0 = 0, c1; c0 < nchunks; c0 = c1) {
+        const uint32_t len = c0 == 0 ? kFirst : kSection;
+        c1 = c0 + len < nchunks ? c0 + len : nchunks;
         hipLaunchKernelGGL((chunk_composite_kernel<PASS, 4>), dim3((c1 - c0 + 3) / 4), dim3(256), 0,
                            ctx->stream, dmean, n, sc, csum, comp, c0, c1);
+        hipLaunchKernelGGL((batch_composite_kernel<4>), dim3((c1 - c0 + kBatch - 1) / kBatch),
+                           dim3(64), 0, ctx->stream, comp, bcomp, c0, c1);
         hipLaunchKernelGGL((stats_walk_kernel<PASS, 4>), dim3(1), dim3(64), 0, ctx->stream, dmean, n,
-                           sc, comp, c0, c1, c1 == nchunks, std_mul);
+                           sc, comp, bcomp, c0, c1, c1 == nchunks, std_mul);
     }
 }
 
@@ -606,6 +727,9 @@ int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std
     double *ssum = reinterpret_cast<double *>(sp);
     unsigned long long *scnt = reinterpret_cast<unsigned long long *>(ssum + nspans);
     float *smax = reinterpret_cast<float *>(scnt + nspans);
+    uintptr_t bp = reinterpret_cast<uintptr_t>(smax + nspans);
+    bp = (bp + 15u) & ~(uintptr_t)15u;
+    Composite *bcomp = reinterpret_cast<Composite *>(bp);
     auto scan = [&](int write_count) {
         hipLaunchKernelGGL(chunk_scan_local_kernel, dim3(nspans), dim3(1024), 0, ctx->stream, csum,
                            ccnt, cmax, nchunks, ssum, scnt, smax, sc, write_count);
@@ -619,11 +743,11 @@ int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std
     // pass 1: mean
     hipLaunchKernelGGL(chunk_sums_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
     scan(1);
-    run_pass<1>(ctx, W, dmean, n, sc, csum, comp, nchunks, std_mul);
+    run_pass<1>(ctx, W, dmean, n, sc, csum, comp, bcomp, nchunks, std_mul);
     // pass 2: variance
     hipLaunchKernelGGL(chunk_sums_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
     scan(0);
-    run_pass<2>(ctx, W, dmean, n, sc, csum, comp, nchunks, std_mul);
+    run_pass<2>(ctx, W, dmean, n, sc, csum, comp, bcomp, nchunks, std_mul);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
@@ -637,7 +761,7 @@ size_t pcrs_sor_stats_workspace(size_t n) {
     return nchunks * (sizeof(double) + (size_t)stats_window(n) * sizeof(Composite) +
                       sizeof(uint32_t) + sizeof(float)) +
            (nchunks / ST_SCAN_SPAN + 2) * (sizeof(double) + sizeof(unsigned long long) + sizeof(float)) +
-           128;
+           (nchunks / 256 + 2) * (size_t)stats_window(n) * sizeof(Composite) + 160;
 }
 
 size_t pcrs_sor_stats_scalars_bytes() { return sizeof(StatsScalars); }

@@ -102,12 +102,20 @@ def main():
         full_host = cols
     shard = [engine.from_numpy(c) for c in cols]
     nq = end - begin
-    outputs = dict(mean=engine.empty(nq), keep=engine.empty(nq, "uint8"), nx=engine.empty(nq),
-                   ny=engine.empty(nq), nz=engine.empty(nq))
+    # With several ranks each one answers a run of whole cells of the replicated index (a compact
+    # region of space) instead of the scattered points it was handed; the runs follow the cell
+    # boundaries, so the buffers leave room for a little imbalance.
+    ownership = "cells" if world > 1 else "index"
+    cap = nq if world == 1 else nq + nq // 8 + 65536
+    outputs = dict(mean=engine.empty(cap), keep=engine.empty(cap, "uint8"), nx=engine.empty(cap),
+                   ny=engine.empty(cap), nz=engine.empty(cap))
+    if world > 1:
+        outputs.update(point=engine.empty(cap, "int32"), mean_by_index=engine.empty(n_total))
 
     def step(want_stats=False):
         return sor_normals_sharded(engine, coll, shard, n_total, K_SOR, STD_MUL, K_NRM,
-                                   (0.0, 0.0, 0.0), outputs, want_stats=want_stats)
+                                   (0.0, 0.0, 0.0), outputs, want_stats=want_stats,
+                                   ownership=ownership)
 
     search_stats = step(want_stats=True)["stats"]  # untimed: how many queries each stage answered
     for _ in range(args.warmup):
@@ -132,6 +140,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed / 1e6
     avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+    nq = int(res["mean"].numel())  # queries this rank answered per step
     achieved = BYTES_PER_POINT * nq / avg_kernel_s / 1e9 if launches else 0.0
 
     icp_line = None
@@ -161,6 +170,8 @@ def main():
                 "workload": f"SOR k={K_SOR} std_mul={STD_MUL} + normals k={K_NRM}, uniform-random cloud, "
                             f"{args.points} points per GPU ({n_total} total), queries sharded over ranks",
                 "points_per_gpu": args.points,
+                "ownership": res["ownership"],
+                "queries_rank0": nq,
                 "n_keep_rank0": int(res["n_keep"]),
                 "threshold": res["thr"],
                 "search_stats_rank0": dict(zip(("cell_walk", "wave_retry", "brute"), search_stats)),

@@ -237,6 +237,26 @@ int pcrs_sor_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint
                          uint32_t k_normals, const float viewpoint[3], float *dmean, float *dnx,
                          float *dny, float *dnz);
 
+/* The same fused search over a run of the index's cell-ordered slots instead of
+ * an index range (no counterpart in the reference: the unit of work for
+ * sharding one cloud over several GPUs by space rather than by input order).
+ * pcrs_index_slot_bounds splits the slots into `parts` runs of whole cells of
+ * nearly equal length: run r is [bounds[r], bounds[r+1]) (host array of
+ * parts + 1 entries; identical on every process that built an index over the
+ * same points).  All bounds are 0 when the index has no cell order to split
+ * (brute-force index, or a cloud with non-finite points).
+ * pcrs_sor_normals_slots_dev answers the queries of one run: dpoint[i] is the
+ * original index of the point in slot slot_begin + i, and dmean / dnx / dny /
+ * dnz[i] are that point's results — the values pcrs_sor_normals_dev writes at
+ * index dpoint[i].  pcrs_scatter_f32_dev is the way back to index order:
+ * dout[dpoint[i]] = dvalues[i]. */
+int pcrs_index_slot_bounds(pcrs_index *index, uint32_t parts, size_t *bounds);
+int pcrs_sor_normals_slots_dev(pcrs_index *index, size_t slot_begin, size_t slot_count,
+                               uint32_t k_sor, uint32_t k_normals, const float viewpoint[3],
+                               uint32_t *dpoint, float *dmean, float *dnx, float *dny, float *dnz);
+int pcrs_scatter_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dpoint, size_t n,
+                         float *dout);
+
 /* estimate_normals_with_viewpoint on host buffers.  k == 0 or n == 0 writes
  * nothing (the reference returns empty vectors, estimate.rs:25-31). */
 int pcrs_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,

@@ -691,6 +691,82 @@ int pcrs_sor_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint
     return run_query(index, q, o, kneed);
 }
 
+int pcrs_index_slot_bounds(pcrs_index *index, uint32_t parts, size_t *bounds) {
+    if (!index) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (!bounds || parts == 0) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "parts must be >= 1");
+    if (index->algo != PCRS_ALGO_GRID || index->nvalid != index->m) {
+        // no cell order to split by (brute-force index, or non-finite points that have no cell)
+        for (uint32_t r = 0; r <= parts; ++r) bounds[r] = 0;
+        return PCRS_OK;
+    }
+    return pcrs_grid_slot_bounds(index, parts, bounds);
+}
+
+int pcrs_sor_normals_slots_dev(pcrs_index *index, size_t slot_begin, size_t slot_count,
+                               uint32_t k_sor, uint32_t k_normals, const float viewpoint[3],
+                               uint32_t *dpoint, float *dmean, float *dnx, float *dny, float *dnz) {
+    if (!index) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (index->algo != PCRS_ALGO_GRID)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "the index has no cell order");
+    if (slot_begin > index->nvalid || slot_count > index->nvalid - slot_begin)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG,
+                            "slot range [%zu, +%zu) exceeds the %zu slots of the index", slot_begin,
+                            slot_count, index->nvalid);
+    const bool want_n = dnx || dny || dnz;
+    if (want_n && !(dnx && dny && dnz))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "normals need all three output columns");
+    if (dmean && k_sor == 0) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_sor must be >= 1");
+    if (want_n && (k_normals == 0 || !viewpoint))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_normals must be >= 1 with a viewpoint");
+    if (slot_count == 0) return PCRS_OK;
+    if (!dpoint) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null point-index output");
+    // the points of the run as explicit queries, already in cell order
+    DevBuf qx, qy, qz;
+    PCRS_HIP_CHECK(ctx, qx.alloc(ctx, slot_count * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, qy.alloc(ctx, slot_count * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, qz.alloc(ctx, slot_count * sizeof(float)));
+    PCRS_TRY(pcrs_grid_slot_slice(index, slot_begin, slot_count, qx.as<float>(), qy.as<float>(),
+                                  qz.as<float>(), dpoint));
+    if (!dmean && !want_n) return PCRS_OK;
+    KnnQuery q;
+    q.qx = qx.as<float>();
+    q.qy = qy.as<float>();
+    q.qz = qz.as<float>();
+    q.nq = slot_count;
+    q.coherent = true;
+    KnnOut o;
+    uint32_t kneed = 1;
+    if (dmean) {
+        if (k_sor == 0xFFFFFFFFu) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_sor too large");
+        o.mean = dmean;
+        o.k_sor = k_sor;
+        kneed = k_sor + 1;
+    }
+    if (want_n) {
+        o.nx = dnx;
+        o.ny = dny;
+        o.nz = dnz;
+        o.k_nrm = k_normals;
+        o.vp[0] = viewpoint[0];
+        o.vp[1] = viewpoint[1];
+        o.vp[2] = viewpoint[2];
+        if (k_normals > kneed) kneed = k_normals;
+    }
+    return run_query(index, q, o, kneed);
+}
+
+int pcrs_scatter_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dpoint, size_t n,
+                         float *dout) {
+    PCRS_TRY(bind_device(ctx));
+    if (n && (!dvalues || !dpoint || !dout))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    return pcrs_launch_scatter_perm(ctx, dvalues, dpoint, n, dout);
+}
+
 int pcrs_sor_mean_dist_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
                            float *dmean) {
     if (!dmean) return PCRS_ERR_INVALID_ARG;

@@ -1402,6 +1402,52 @@ int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, ui
     return PCRS_OK;
 }
 
+// bounds[r] = first slot of the first cell that starts at or behind slot r * nvalid / parts:
+// a split of the sorted slots into `parts` runs of whole cells (the order of the points inside
+// a cell is not reproducible between two builds, the cell boundaries are)
+__global__ void slot_bounds_kernel(const uint32_t *cell_start, uint32_t ncell, uint32_t nvalid,
+                                   uint32_t parts, uint32_t *bounds) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > parts) return;
+    const uint32_t target = (uint32_t)(((unsigned long long)r * nvalid) / parts);
+    uint32_t lo = 0, hi = ncell;  // smallest c with cell_start[c] >= target; cell_start[ncell] = nvalid
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (cell_start[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    bounds[r] = r == parts ? nvalid : cell_start[lo];
+}
+
+int pcrs_grid_slot_bounds(pcrs_index *ix, uint32_t parts, size_t *bounds) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (ix->algo != PCRS_ALGO_GRID || ix->nvalid == 0)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "index has no grid");
+    DevBuf d;
+    PCRS_HIP_CHECK(ctx, d.alloc(ctx, ((size_t)parts + 1) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(slot_bounds_kernel, dim3((parts + 64) / 64), dim3(64), 0, ctx->stream,
+                       ix->cell_start.as<uint32_t>(), ix->ncell, (uint32_t)ix->nvalid, parts,
+                       d.as<uint32_t>());
+    std::vector<uint32_t> h((size_t)parts + 1);
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t r = 0; r <= parts; ++r) bounds[r] = h[r];
+    return PCRS_OK;
+}
+
+int pcrs_grid_slot_slice(pcrs_index *ix, size_t begin, size_t count, float *ox, float *oy,
+                         float *oz, uint32_t *perm) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (ix->algo != PCRS_ALGO_GRID || begin > ix->nvalid || count > ix->nvalid - begin)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "slot range outside the grid");
+    if (count == 0) return PCRS_OK;
+    hipLaunchKernelGGL(unpack_sorted_kernel, dim3((unsigned)((count + GB_THREADS - 1) / GB_THREADS)),
+                       dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>() + begin,
+                       (uint32_t)count, ox, oy, oz, perm);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
 // Cube half-width (cells) that is certain to cover a ball of the given radius around any query,
 // with the same allowance for f32 cell assignment as the neighbour-search certification.
 static int radius_cells(const pcrs_index *ix, float radius) {

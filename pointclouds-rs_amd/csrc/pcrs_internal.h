@@ -229,6 +229,11 @@ int pcrs_launch_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y,
 // Writes the points in cell order (ties inside a cell by original index) as columns, with the
 // permutation sorted position -> original index.  Needs algo == GRID; all nvalid points.
 int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm);
+// Split of the sorted slots into `parts` runs of whole cells (bounds[parts + 1], host memory;
+// one read-back) and the columns + original indices of a run of slots.
+int pcrs_grid_slot_bounds(pcrs_index *ix, uint32_t parts, size_t *bounds);
+int pcrs_grid_slot_slice(pcrs_index *ix, size_t begin, size_t count, float *ox, float *oy,
+                         float *oz, uint32_t *perm);
 int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed);
 // consumer defaults for the non-finite queries of a self-query range (knn_bf.hip)
 int pcrs_launch_invalid_defaults(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,

@@ -752,9 +752,16 @@ int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std
     return PCRS_OK;
 }
 
-// Binades per chunk composite: a sum of more than a few million similar elements can stall
-// below the exact prefix, which the window of four binades follows; short sums use one.
-static int stats_window(size_t n) { return n > (size_t)4 << 20 ? 4 : 1; }
+// Binades per chunk composite.  After i adds the f32 sum is within a factor 1 -+ i 2^-24 of the
+// exact prefix; elements far below half an ulp (squared deviations) all round the same way, so
+// the bound is reached.  Up to 2^20 elements that is 6 %: one binade, predicted from the prefix,
+// with a few element-wise chunks around every crossing.  Longer sums take a window of four
+// (PCRS_STATS_WINDOW=1|4 overrides the choice, for experiments).
+static int stats_window(size_t n) {
+    static const char *force = getenv("PCRS_STATS_WINDOW");
+    if (force && (force[0] == '1' || force[0] == '4')) return force[0] - '0';
+    return n > (size_t)1 << 20 ? 4 : 1;
+}
 
 size_t pcrs_sor_stats_workspace(size_t n) {
     const size_t nchunks = (n + ST_CHUNK - 1) / ST_CHUNK + 1;

@@ -83,6 +83,10 @@ SIGNATURES = {
     "pcrs_sor": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_float, _V, c_size_p, c_float_p, _V]),
     "pcrs_normals_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, c_float_p, _V, _V, _V]),
     "pcrs_sor_normals_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, c_float_p, _V, _V, _V, _V]),
+    "pcrs_index_slot_bounds": (C.c_int, [_V, C.c_uint32, c_size_p]),
+    "pcrs_sor_normals_slots_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32,
+                                             c_float_p, _V, _V, _V, _V, _V]),
+    "pcrs_scatter_f32_dev": (C.c_int, [_V, _V, _V, C.c_size_t, _V]),
     "pcrs_normals": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, c_float_p, _V, _V, _V]),
     "pcrs_sor_normals": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_float, C.c_uint32, c_float_p, _V, c_size_p, c_float_p, _V, _V, _V]),
     "pcrs_apply_transform": (C.c_int, [_V] + _F3 + [C.c_size_t, c_float_p, c_float_p, _V, _V, _V]),

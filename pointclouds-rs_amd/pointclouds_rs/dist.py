@@ -10,6 +10,10 @@ contiguous index range of the cloud, resident in its HBM:
   3. all-gather the per-point mean distances (4 B/pt); every rank derives the same global
      threshold with the reference's summation order and masks its own range.
 
+Which queries a rank answers is a choice (`ownership`): the points it was handed (results in
+input order, but scattered all over the replicated index), or a run of whole cells of the index
+(a compact region of space; the results carry their global point indices).
+
 ICP shards the source; each iteration all-reduces the PCRS_ICP_NSUMS f64 partial sums and every
 rank solves the same small system, so no transform broadcast is needed.
 
@@ -81,6 +85,27 @@ class HipEngine:
         self.ctx.check(self.lib.pcrs_sor_normals_dev(index, q_begin, q_count, k_sor, k_nrm, vp,
                                                      self._p(mean), self._p(nx), self._p(ny),
                                                      self._p(nz)))
+
+    # -- the same over runs of cell-ordered slots (ownership by space)
+    def slot_bounds(self, index, parts):
+        """[bounds[0], ..., bounds[parts]] of the runs of whole cells; all 0 when the index has
+        no cell order to split."""
+        b = (C.c_size_t * (parts + 1))()
+        self.ctx.check(self.lib.pcrs_index_slot_bounds(index, parts, b))
+        return [int(v) for v in b]
+
+    def sor_normals_slots(self, index, s_begin, s_count, k_sor, k_nrm, viewpoint, point, mean,
+                          nx, ny, nz):
+        vp = (C.c_float * 3)(*[float(v) for v in viewpoint])
+        self.ctx.check(self.lib.pcrs_sor_normals_slots_dev(index, s_begin, s_count, k_sor, k_nrm,
+                                                           vp, self._p(point), self._p(mean),
+                                                           self._p(nx), self._p(ny), self._p(nz)))
+
+    def scatter(self, values, point, out):
+        """out[point[i]] = values[i]"""
+        self.ctx.check(self.lib.pcrs_scatter_f32_dev(self.ctx.handle, self._p(values),
+                                                     self._p(point), values.numel(),
+                                                     self._p(out)))
 
     def threshold(self, mean_full, std_mul):
         thr = C.c_float()
@@ -211,45 +236,77 @@ class Collectives:
 
 def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
                         viewpoint=(0.0, 0.0, 0.0), outputs=None, algo=_ffi.ALGO_AUTO,
-                        want_stats=False):
+                        want_stats=False, ownership="index"):
     """SOR + normals of a cloud whose points are sharded over ranks in index order.
 
-    shard: (x, y, z) tensors of this rank's points.  Returns a dict with this rank's
-    keep mask, means, normals, the global threshold and kept count of the shard.
-    `outputs` may carry preallocated tensors (mean, keep, nx, ny, nz) to avoid allocation;
+    shard: (x, y, z) tensors of this rank's points.  Returns a dict with the keep mask, means and
+    normals of the points this rank answered, the global threshold and the kept count among them.
+    `outputs` may carry preallocated tensors (mean, keep, nx, ny, nz, point) to avoid allocation;
     `want_stats` adds the search-stage counters of this call (a device read-back).
+
+    ownership="index": the rank answers the points it holds, results in their order
+    (result["begin"], result["end"] = its index range).
+    ownership="cells": the rank answers a run of whole grid cells of the replicated index —
+    a compact region of space, so its search touches 1/world of the index instead of all of it.
+    result["point"] holds the global index of every answered point (int32 bit pattern of a
+    uint32), the other arrays are in the same order; the runs of all ranks partition the cloud.
+    Falls back to "index" when the index has no cell order (tiny or non-finite clouds);
+    result["ownership"] tells which one ran.
     """
     torch = engine.torch
     world, rank = coll.world, coll.rank
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0]
               for r in range(world)]
     begin, end = shard_range(n_total, world, rank)
-    nq = end - begin
-    assert shard[0].numel() == nq, "shard length does not match its index range"
+    assert shard[0].numel() == end - begin, "shard length does not match its index range"
+    assert ownership in ("index", "cells")
     full = [coll.all_gather_var(torch, c, counts) for c in shard]
     if outputs is None:
         outputs = {}
-    mean = outputs.get("mean") if outputs.get("mean") is not None else engine.empty(nq)
-    keep = outputs.get("keep") if outputs.get("keep") is not None else engine.empty(nq, "uint8")
+
+    def buf(name, n, dtype="float32"):
+        t = outputs.get(name)
+        return t[:n] if t is not None and t.numel() >= n else engine.empty(n, dtype)
+
     want_n = k_nrm > 0
-    nx = ny = nz = None
-    if want_n:
-        nx = outputs.get("nx") if outputs.get("nx") is not None else engine.empty(nq)
-        ny = outputs.get("ny") if outputs.get("ny") is not None else engine.empty(nq)
-        nz = outputs.get("nz") if outputs.get("nz") is not None else engine.empty(nq)
     k_hint = max(k_sor + 1 if k_sor else 0, k_nrm)
     index = engine.build_index(full[0], full[1], full[2], k_hint, algo)
     try:
-        engine.sor_normals_range(index, begin, nq, k_sor, k_nrm, viewpoint,
-                                 mean if k_sor else None, nx, ny, nz)
+        bounds = engine.slot_bounds(index, world) if ownership == "cells" else None
+        if bounds is not None and bounds[-1] != n_total:
+            bounds, ownership = None, "index"
+        if bounds is None:
+            nq = end - begin
+            own_counts = counts
+        else:
+            own_counts = [bounds[r + 1] - bounds[r] for r in range(world)]
+            nq = own_counts[rank]
+        # preallocated outputs are sized for the largest run a rank can get
+        mean, keep = buf("mean", nq), buf("keep", nq, "uint8")
+        nx = ny = nz = point = None
+        if want_n:
+            nx, ny, nz = buf("nx", nq), buf("ny", nq), buf("nz", nq)
+        if bounds is None:
+            engine.sor_normals_range(index, begin, nq, k_sor, k_nrm, viewpoint,
+                                     mean if k_sor else None, nx, ny, nz)
+        else:
+            point = buf("point", nq, "int32")
+            engine.sor_normals_slots(index, bounds[rank], nq, k_sor, k_nrm, viewpoint, point,
+                                     mean if k_sor else None, nx, ny, nz)
         # reading the stage counters back waits for the search: only on request
         stats = engine.index_stats(index) if want_stats else None
     finally:
         engine.destroy_index(index)
     result = dict(mean=mean, keep=keep, nx=nx, ny=ny, nz=nz, thr=math.nan, n_keep=0, stats=stats,
-                  begin=begin, end=end)
+                  begin=begin, end=end, point=point, ownership=ownership)
     if k_sor:
-        mean_full = coll.all_gather_var(torch, mean, counts)
+        mean_full = coll.all_gather_var(torch, mean, own_counts)
+        if bounds is not None:
+            # the threshold is a sequential sum over the means in index order
+            point_full = coll.all_gather_var(torch, point, own_counts)
+            by_index = buf("mean_by_index", n_total)
+            engine.scatter(mean_full, point_full, by_index)
+            mean_full = by_index
         thr, ok, n_keep = engine.select(mean_full, std_mul, mean, keep)
         if ok:
             result["thr"] = thr

@@ -6,6 +6,8 @@ eng = HipEngine(0)
 rng = np.random.default_rng(3)
 n = int(float(sys.argv[1]))
 m = rng.gamma(9.0, 0.13, n).astype(np.float32)
+if len(sys.argv) > 2 and sys.argv[2] == "mixed":  # three quarters of the values exactly 1.0
+    m[rng.random(n) < 0.75] = 1.0
 d = eng.from_numpy(m)
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()

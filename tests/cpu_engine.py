@@ -40,6 +40,42 @@ class CpuEngine:
             for dst, src in zip((nx, ny, nz), n):
                 dst.copy_(torch.from_numpy(src[sl].copy()))
 
+    # "cell order" of the stand-in: points sorted by x (cells = unit-wide slabs of x)
+    def _order(self, index):
+        x = index[0]
+        if not np.isfinite(np.stack(index)).all() or len(x) < 64:
+            return None
+        return np.argsort(x, kind="stable")
+
+    def slot_bounds(self, index, parts):
+        order = self._order(index)
+        if order is None:
+            return [0] * (parts + 1)
+        cells = np.floor(index[0][order]).astype(np.int64)
+        n = len(order)
+        starts = np.flatnonzero(np.r_[True, cells[1:] != cells[:-1]])  # first slot of every cell
+        out = []
+        for r in range(parts):
+            t = r * n // parts
+            i = np.searchsorted(starts, t, side="left")
+            out.append(int(starts[i]) if i < len(starts) else n)
+        return out + [n]
+
+    def sor_normals_slots(self, index, s_begin, s_count, k_sor, k_nrm, viewpoint, point, mean,
+                          nx, ny, nz):
+        x, y, z = index
+        sel = self._order(index)[s_begin:s_begin + s_count]
+        point.copy_(torch.from_numpy(sel.astype(np.uint32).view(np.int32).copy()))
+        if mean is not None:
+            mean.copy_(torch.from_numpy(self.o.sor_mean_dist(x, y, z, k_sor, algo=1)[sel].copy()))
+        if nx is not None:
+            n = self.o.normals(x, y, z, k_nrm, viewpoint, algo=1)
+            for dst, src in zip((nx, ny, nz), n):
+                dst.copy_(torch.from_numpy(src[sel].copy()))
+
+    def scatter(self, values, point, out):
+        out.numpy()[point.numpy().view(np.uint32)] = values.numpy()
+
     def threshold(self, mean_full, std_mul):
         ok, thr, _, _ = self.o.sor_threshold(mean_full.numpy(), std_mul)
         return (thr if ok else float("nan")), ok

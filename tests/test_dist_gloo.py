@@ -46,6 +46,12 @@ def _worker(rank, world, port, n_total, q):
     out = dict(rank=rank, begin=b, end=e, thr=res["thr"], n_keep=res["n_keep"],
                keep=res["keep"].numpy().copy(), mean=res["mean"].numpy().copy(),
                nx=res["nx"].numpy().copy())
+    # the same cloud with ownership by runs of cells: results come with their point indices
+    rc = sor_normals_sharded(eng, coll, shard, n_total, 8, 1.0, 8, ownership="cells")
+    out["cells"] = dict(ownership=rc["ownership"], thr=rc["thr"], n_keep=rc["n_keep"],
+                        point=rc["point"].numpy().view(np.uint32).copy(),
+                        keep=rc["keep"].numpy().copy(), mean=rc["mean"].numpy().copy(),
+                        nx=rc["nx"].numpy().copy())
     # sharded ICP (point-to-plane), source split over the ranks, target replicated
     tgt = synth.hemisphere(1500, 99, 5.0)
     tn = o.normals(*tgt, 12, algo=1)
@@ -87,6 +93,18 @@ def test_sharded_matches_single_process(oracle):
         assert np.array_equal(o["mean"], mean[b:e])
         assert np.array_equal(o["keep"].astype(bool), keep[b:e])
         assert np.array_equal(o["nx"], nx[b:e])
+    # ownership by cells: the runs of the ranks partition the cloud, every answer is the
+    # single-process answer of the point it names
+    pts = np.concatenate([o["cells"]["point"] for o in outs])
+    assert np.array_equal(np.sort(pts), np.arange(n_total, dtype=np.uint32))
+    assert sum(o["cells"]["n_keep"] for o in outs) == n_keep
+    for o in outs:
+        c = o["cells"]
+        assert c["ownership"] == "cells" and len(c["point"]) > 0
+        assert np.float32(c["thr"]) == np.float32(thr)
+        assert np.array_equal(c["mean"], mean[c["point"]])
+        assert np.array_equal(c["keep"].astype(bool), keep[c["point"]])
+        assert np.array_equal(c["nx"], nx[c["point"]])
     # ICP: both ranks hold the same transform, equal to the single-process oracle run
     tgt = synth.hemisphere(1500, 99, 5.0)
     tn = oracle.normals(*tgt, 12, algo=1)

@@ -508,6 +508,83 @@ def test_query_subrange_equals_full(oracle):
         eng.destroy_index(ix)
 
 
+def test_slot_runs_equal_full(oracle):
+    """Ownership by space: the runs of whole cells that pcrs_index_slot_bounds hands out
+    partition the cloud, and the answers of a run are exactly the single-call answers of the
+    points it names (means bit for bit, normals within tolerance)."""
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine(0)
+    torch = eng.torch
+    dx, dy, dz = (np.nan_to_num(c, nan=1.5, posinf=2.5, neginf=0.5) for c in gen.degenerate_cloud(300, 7))
+    kx, ky, kz = gen.kitti_scene(5, 20000, 3000, 500)
+    ux, uy, uz = gen.uniform_cloud(30000, 11)
+    x, y, z = (np.concatenate(c).astype(F) for c in ((dx, kx, ux), (dy, ky, uy), (dz, kz, uz)))
+    n = len(x)
+    cols = [eng.from_numpy(c) for c in (x, y, z)]
+    rmean = oracle.sor_mean_dist(x, y, z, 16, algo=1)
+    rn = oracle.normals(x, y, z, 16, (1.0, 2.0, 3.0), algo=1)
+    ix = eng.build_index(*cols, 17, 2)
+    for parts in (1, 2, 3, 8, 50):
+        bounds = eng.slot_bounds(ix, parts)
+        assert bounds[0] == 0 and bounds[-1] == n and bounds == sorted(bounds)
+        seen = np.zeros(n, dtype=np.int64)
+        by_index = eng.empty(n)
+        for r in range(parts):
+            b, c = bounds[r], bounds[r + 1] - bounds[r]
+            point = eng.empty(c, "int32"); mean = eng.empty(c)
+            nx = eng.empty(c); ny = eng.empty(c); nz = eng.empty(c)
+            eng.sor_normals_slots(ix, b, c, 16, 16, (1.0, 2.0, 3.0), point, mean, nx, ny, nz)
+            eng.scatter(mean, point, by_index)
+            torch.cuda.synchronize()
+            pt = point.cpu().numpy().view(np.uint32)
+            seen[pt] += 1
+            assert np.array_equal(mean.cpu().numpy().view(np.uint32), rmean[pt].view(np.uint32))
+            for got, ref in zip((nx, ny, nz), rn):
+                assert np.abs(got.cpu().numpy().astype(np.float64) - ref[pt]).max(initial=0.0) <= 1e-5
+        assert (seen == 1).all()
+        assert np.array_equal(by_index.cpu().numpy().view(np.uint32), rmean.view(np.uint32))
+    # a second build may order the points inside a cell differently, never the cells
+    ix2 = eng.build_index(*cols, 17, 2)
+    assert eng.slot_bounds(ix2, 8) == eng.slot_bounds(ix, 8)
+    eng.destroy_index(ix2)
+    eng.destroy_index(ix)
+    # no cell order: brute-force index, cloud with a non-finite point
+    ixb = eng.build_index(*cols, 17, 1)
+    assert eng.slot_bounds(ixb, 4) == [0] * 5
+    eng.destroy_index(ixb)
+    xn = x.copy(); xn[17] = np.nan
+    ixn = eng.build_index(eng.from_numpy(xn), cols[1], cols[2], 17, 2)
+    assert eng.slot_bounds(ixn, 4) == [0] * 5
+    eng.destroy_index(ixn)
+
+
+def test_sharded_driver_cells_single_rank(oracle):
+    """pointclouds_rs.dist with ownership by cells on one rank: the whole pipeline (search over
+    the run, scatter of the means to index order, exact threshold, mask) against the oracle."""
+    from pointclouds_rs.dist import Collectives, HipEngine, sor_normals_sharded
+
+    eng = HipEngine(0)
+    x, y, z = gen.kitti_scene(9, 30000, 4000, 800)
+    n = len(x)
+    shard = [eng.from_numpy(c) for c in (x, y, z)]
+    keep, n_keep, thr, mean = oracle.sor(x, y, z, 16, 1.0, algo=1)
+    rn = oracle.normals(x, y, z, 16, algo=1)
+    res = sor_normals_sharded(eng, Collectives(None), shard, n, 16, 1.0, 16, ownership="cells")
+    assert res["ownership"] == "cells"
+    pt = res["point"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(np.sort(pt), np.arange(n, dtype=np.uint32))
+    assert F(res["thr"]).view(np.uint32) == F(thr).view(np.uint32) and res["n_keep"] == n_keep
+    assert np.array_equal(res["mean"].cpu().numpy().view(np.uint32), mean[pt].view(np.uint32))
+    assert np.array_equal(res["keep"].cpu().numpy().astype(bool), keep[pt])
+    for got, ref in zip((res["nx"], res["ny"], res["nz"]), rn):
+        assert np.abs(got.cpu().numpy().astype(np.float64) - ref[pt]).max() <= 1e-5
+    # a cloud without cell order falls back to ownership by index
+    xs = [eng.from_numpy(c[:40]) for c in (x, y, z)]
+    r2 = sor_normals_sharded(eng, Collectives(None), xs, 40, 8, 1.0, 8, ownership="cells")
+    assert r2["ownership"] == "index" and r2["point"] is None
+
+
 def test_large_cloud_parity(oracle):
     """6 M points (the benchmark's per-GPU size times six): means, threshold and mask bit-exact,
     normals within tolerance on a sample; also the one-level (global-atomic) sort, which grids

@@ -85,7 +85,8 @@ def test_select_equals_threshold_then_mask(engine, oracle, name):
     assert not ok and np.isnan(thr) and n_keep == 0 and not keep.cpu().numpy().any()
 
 
-@pytest.mark.parametrize("name", ["stall20M", "lognormal6M", "tiny5M"])
+@pytest.mark.parametrize("name", ["stall20M", "lognormal6M", "tiny5M", "mixed4M", "mixed1.1M",
+                                  "ascending9M", "mixed1M"])
 def test_threshold_bit_exact_long_sums(engine, oracle, name):
     """Sums long enough for the sequential f32 sum to fall behind the exact sum (it stalls once
     the elements are below half an ulp): the composites are then built for a window of binades."""
@@ -94,8 +95,16 @@ def test_threshold_bit_exact_long_sums(engine, oracle, name):
         m = rng.uniform(0.5, 1.5, 20_000_000).astype(F)
     elif name == "lognormal6M":
         m = rng.lognormal(0.0, 1.5, 6_000_000).astype(F)
-    else:
+    elif name == "tiny5M":
         m = (rng.uniform(0.0, 1.0, 5_000_000) * 1e-12).astype(F)
+    elif name.startswith("mixed"):
+        # three quarters of the values identical: their squared deviations are far below half an
+        # ulp of the variance sum and all round the same way (the largest drift the sum allows)
+        n = {"mixed4M": 4_000_000, "mixed1.1M": 1_100_000, "mixed1M": 1_000_000}[name]
+        m = rng.gamma(9.0, 0.13, n).astype(F)
+        m[rng.random(n) < 0.75] = 1.0
+    else:  # sorted input, just past the unanchored first section of 2^23 elements
+        m = np.sort(rng.gamma(2.0, 0.5, 9_000_000).astype(F))
     m[::100003] = np.inf
     for mul in (1.0,):
         ok_ref, thr_ref, _, _ = oracle.sor_threshold(m, mul)

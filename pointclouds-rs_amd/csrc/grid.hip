@@ -269,8 +269,26 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     const uint32_t begin = table[(size_t)b * sp.nblk];
     const uint32_t end = table[(size_t)(b + 1) * sp.nblk];  // the scan's total closes the table
     for (uint32_t t = threadIdx.x; t < cpb; t += GB_THREADS) cnt[t] = 0;
+    // the first FINE_HELD points of every thread stay in registers between the counting and the
+    // placing pass (all their loads are in flight together); longer buckets are read twice
+    constexpr int FINE_HELD = 8;
+    float4 held[FINE_HELD];
+    uint32_t held_cell[FINE_HELD];
+#pragma unroll
+    for (int h = 0; h < FINE_HELD; ++h) {
+        const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+        if (i < end) held[h] = tmp[i];
+    }
     __syncthreads();
-    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
+#pragma unroll
+    for (int h = 0; h < FINE_HELD; ++h) {
+        const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+        if (i < end) {
+            held_cell[h] = cell_index(sp.g, held[h].x, held[h].y, held[h].z) - cell0;
+            atomicAdd(&cnt[held_cell[h]], 1u);
+        }
+    }
+    for (uint32_t i = begin + threadIdx.x + FINE_HELD * GB_THREADS; i < end; i += GB_THREADS) {
         const float4 p = tmp[i];
         atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u);
     }
@@ -308,13 +326,35 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
         if (f < cpb) {
             const uint32_t c = cnt[f];
             cnt[f] = run;  // becomes the write cursor of the cell
-            if (f < ncl) cell_start[cell0 + f] = run;
             run += c;
         }
     }
     if (b == sp.nb - 1 && threadIdx.x == 0) cell_start[sp.ncell] = end;
     __syncthreads();
-    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
+    // the cell starts leave through consecutive lanes (each thread scanned consecutive cells)
+    for (uint32_t t = threadIdx.x; t < ncl; t += GB_THREADS) cell_start[cell0 + t] = cnt[t];
+    __syncthreads();
+    // A bucket that fits the staging array is put in order in LDS and leaves as one linear copy:
+    // thousands of blocks each scattering 16-byte points over their own window of the output
+    // overflow the L2 once the windows together exceed it, and every partial line costs a
+    // read-modify-write.
+    __shared__ float4 stage[FINE_HELD * GB_THREADS];
+    if (end - begin <= FINE_HELD * GB_THREADS) {
+#pragma unroll
+        for (int h = 0; h < FINE_HELD; ++h) {
+            const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+            if (i < end) stage[atomicAdd(&cnt[held_cell[h]], 1u) - begin] = held[h];
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < end - begin; t += GB_THREADS) spts[begin + t] = stage[t];
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < FINE_HELD; ++h) {
+        const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+        if (i < end) spts[atomicAdd(&cnt[held_cell[h]], 1u)] = held[h];
+    }
+    for (uint32_t i = begin + threadIdx.x + FINE_HELD * GB_THREADS; i < end; i += GB_THREADS) {
         const float4 p = tmp[i];
         const uint32_t at = atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u);
         spts[at] = p;
@@ -1188,7 +1228,12 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
     // experiments only: PCRS_GRID_SORT=atomic keeps the one-level sort
     if (const char *e = getenv("PCRS_GRID_SORT"))
         if (e[0] == 'a') return false;
-    const uint32_t nb_max = ncell <= (1024u << FINE_MAX_SHIFT) ? 1024u : 8192u;
+    // Buckets of about 2000 points: the level-2 block then holds its bucket in registers and
+    // LDS (one read, one linear write).  Few large buckets leave most of the chip idle and turn
+    // level 2 into long serial loops; the table of per-block counts bounds their number.
+    uint32_t nb_max = 1024u;
+    if (m / 1536u > nb_max) nb_max = m / 1536u < 8192u ? m / 1536u : 8192u;
+    if (ncell > (nb_max << FINE_MAX_SHIFT)) nb_max = 8192u;
     uint32_t shift = 0;
     while (((ncell + (1u << shift) - 1) >> shift) > nb_max) ++shift;
     if (shift > FINE_MAX_SHIFT) return false;
@@ -1197,6 +1242,9 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
     sp->nb = (ncell + (1u << shift) - 1) >> shift;
     sp->ncell = ncell;
     uint32_t nblk = (m + 4095) / 4096;
+    // at most about 4 M table entries (nb x nblk), never more than 2048 level-1 blocks
+    const uint32_t cap = ((4u << 20) / sp->nb) > 256u ? (4u << 20) / sp->nb : 256u;
+    if (nblk > cap) nblk = cap;
     if (nblk > 2048) nblk = 2048;
     if (nblk == 0) nblk = 1;
     uint32_t per = (m + nblk - 1) / nblk;
@@ -1304,10 +1352,13 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         const bool two_level = plan_sort(g, ncell, m, &sp);
         if (two_level) {
             // the whole sort is cheaper than one pass of global atomics, so every attempt sorts
-            if (!table.p) {
-                PCRS_HIP_CHECK(ctx, table.alloc(ctx, ((size_t)8192 * sp.nblk + 8) * sizeof(uint32_t)));
+            const size_t entries = (size_t)sp.nb * sp.nblk;  // differs between attempts
+            if (table.bytes < (entries + 8) * sizeof(uint32_t)) {
+                PCRS_HIP_CHECK(ctx, table.alloc(ctx, (entries + entries / 4 + 8) * sizeof(uint32_t)));
                 PCRS_HIP_CHECK(ctx, table_sums.alloc(
-                                        ctx, (((size_t)8192 * sp.nblk) / SCAN_BLOCK + 2) * sizeof(uint32_t)));
+                                        ctx, ((entries + entries / 4) / SCAN_BLOCK + 2) * sizeof(uint32_t)));
+            }
+            if (!tmp.p) {
                 PCRS_HIP_CHECK(ctx, tmp.alloc(ctx, nvalid * sizeof(float4)));
                 PCRS_HIP_CHECK(ctx, sorted.alloc(ctx, nvalid * sizeof(float4)));
             }

@@ -224,26 +224,34 @@ __device__ __forceinline__ Composite compose(const Composite &f, const Composite
     return h;
 }
 
-// the function S -> S + a[S & 1] of one element x >= 0 in the binade with ulp 2^(e-23)
+// the function S -> S + a[S & 1] of one element x >= 0 in the binade with ulp 2^(e-23):
+// x / ulp = m 2^sh from the bits of x; X = its integer part, the remainder decides the rounding
 __device__ __forceinline__ Composite element_function(float x, int e) {
     Composite f;
     f.e = e;
     f.pad = 0;
-    const double t = ldexp((double)x, 23 - e);  // x / ulp, exact
-    if (t >= (double)ST_SAT) {
-        f.a0 = f.a1 = ST_SAT;
+    const uint32_t bits = __float_as_uint(x);
+    const uint32_t ex = bits >> 23, mant = bits & 0x7FFFFFu;
+    const uint32_t m = ex ? (mant | 0x800000u) : mant;  // subnormals have no hidden bit
+    const int sh = (int)(ex ? ex : 1u) - 127 - e;
+    if (sh >= 0) {  // a whole number of ulps
+        const uint32_t X = sh >= 7 ? ST_SAT : (m << sh);
+        f.a0 = f.a1 = min(X, ST_SAT);
         return f;
     }
-    const double fl = floor(t);
-    const double fr = t - fl;
-    const uint32_t X = (uint32_t)fl;
-    if (fr < 0.5) {
+    const int r = -sh;
+    if (r >= 25) {  // below half an ulp
+        f.a0 = f.a1 = 0;
+        return f;
+    }
+    const uint32_t X = m >> r, rem = m & ((1u << r) - 1u), half = 1u << (r - 1);
+    if (rem < half) {
         f.a0 = f.a1 = X;
-    } else if (fr > 0.5) {
+    } else if (rem > half) {
         f.a0 = f.a1 = X + 1u;
     } else {  // tie: round to even
-        f.a0 = X + ((X & 1u) ? 1u : 0u);         // S even: S + X odd iff X odd
-        f.a1 = X + ((X & 1u) ? 0u : 1u);         // S odd:  S + X odd iff X even
+        f.a0 = X + (X & 1u);          // S even: S + X odd iff X odd
+        f.a1 = X + ((X & 1u) ^ 1u);   // S odd:  S + X odd iff X even
     }
     return f;
 }

@@ -7,8 +7,9 @@ contiguous index range of the cloud, resident in its HBM:
      (100 M points = 1.2 GB, far below 288 GB);
   2. build the search index over the whole cloud and answer the rank's own queries
      (fused SOR mean distance + normals, one neighbour search);
-  3. all-gather the per-point mean distances (4 B/pt); every rank derives the same global
-     threshold with the reference's summation order and masks its own range.
+  3. all-gather the per-point mean distances (4 B/pt; with ownership by cells a sum over ranks
+     of vectors that are zero outside the rank's own points); every rank derives the same
+     global threshold with the reference's summation order and masks its own points.
 
 Which queries a rank answers is a choice (`ownership`): the points it was handed (results in
 input order, but scattered all over the replicated index), or a run of whole cells of the index
@@ -216,6 +217,11 @@ class Collectives:
         self.dist.all_gather_into_tensor(out, padded)
         return torch.cat([out[r * maxc: r * maxc + counts[r]] for r in range(self.world)])
 
+    def all_reduce_sum(self, t):
+        """In-place sum of a tensor over ranks."""
+        if self.world > 1:
+            self.dist.all_reduce(t)
+
     def all_reduce_sum_f64(self, torch, arr, device):
         """Sums a small float64 NumPy vector over ranks (rank-order independent result)."""
         if self.world == 1:
@@ -300,13 +306,16 @@ def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
     result = dict(mean=mean, keep=keep, nx=nx, ny=ny, nz=nz, thr=math.nan, n_keep=0, stats=stats,
                   begin=begin, end=end, point=point, ownership=ownership)
     if k_sor:
-        mean_full = coll.all_gather_var(torch, mean, own_counts)
-        if bounds is not None:
-            # the threshold is a sequential sum over the means in index order
-            point_full = coll.all_gather_var(torch, point, own_counts)
-            by_index = buf("mean_by_index", n_total)
-            engine.scatter(mean_full, point_full, by_index)
-            mean_full = by_index
+        # the threshold is a sequential sum over the means in index order
+        if bounds is None:
+            mean_full = coll.all_gather_var(torch, mean, own_counts)
+        else:
+            # every rank drops its means at their indices into a zeroed vector; the sum over
+            # ranks (x + 0 + ... + 0, exact in any order) is the vector of all means
+            mean_full = buf("mean_by_index", n_total)
+            mean_full.zero_()
+            engine.scatter(mean, point, mean_full)
+            coll.all_reduce_sum(mean_full)
         thr, ok, n_keep = engine.select(mean_full, std_mul, mean, keep)
         if ok:
             result["thr"] = thr

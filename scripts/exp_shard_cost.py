@@ -10,7 +10,8 @@ from pointclouds_rs.dist import HipEngine
 
 eng = HipEngine(0)
 mode = sys.argv[1] if len(sys.argv) > 1 else "index"  # "index" or "cells"
-for world in (1, 2, 4, 8):
+worlds = [int(sys.argv[2])] if len(sys.argv) > 2 else [1, 2, 4, 8]
+for world in worlds:
     n = world * 1_000_000
     side = np.float32(100.0 * world ** (1.0 / 3.0))
     cols = [eng.from_numpy((synth.uniform01(42, n, a) * side).astype(np.float32)) for a in range(3)]
@@ -38,8 +39,9 @@ for world in (1, 2, 4, 8):
             eng.sor_normals_slots(ix, bounds[0], c, 16, 16, (0.0, 0.0, 0.0), point[:c], mean[:c],
                                   nx[:c], ny[:c], nz[:c])
             torch.cuda.synchronize(); t2 = time.perf_counter()
-            gathered[:c] = mean[:c]
-            eng.scatter(gathered, point_full, mean_full)
+            mean_full.zero_()  # the sum over ranks of these vectors is the collective's part
+            eng.scatter(mean[:c], point[:c], mean_full)
+            mean_full += gathered  # stands in for the other ranks' means
         thr, ok, nk = eng.select(mean_full, 1.0, mean, keep)
         torch.cuda.synchronize(); t3 = time.perf_counter()
         eng.destroy_index(ix)

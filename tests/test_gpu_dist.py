@@ -46,6 +46,11 @@ def _worker(rank, world, port, q):
             out = Collectives.all_gather_var(self, torch, local.cpu(), counts)
             return out.to(local.device)
 
+        def all_reduce_sum(self, t):
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -634,9 +634,12 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 }
 
 // Wave-cooperative walk over the rows of a box of cells: f(p, valid, slot) is called by the whole
-// wave for every 64-point piece of every row.  The lanes first fetch the row ranges in parallel
-// (one memory latency for up to 64 rows), then the points of eight rows are requested before any
-// is used: a retried query is a single wave, so nothing else hides its load latency.
+// wave for every 64-point piece of the box.  The lanes fetch the row ranges in parallel (one
+// memory latency for up to 64 rows) and a scan of the row lengths turns the rows into one list;
+// every lane finds the row of its list position with a binary search over the lanes' prefixes
+// (ds_bpermute), so a box of many short rows — a surface seen through a large cube — costs a few
+// full-width steps instead of one step per row.  Four steps are requested before any is used: a
+// retried query is a single wave, so nothing else hides its load latency.
 template <class F>
 __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int y0, int y1, int z0,
                                           int z1, int lane, F f) {
@@ -653,37 +656,34 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
             ms0 = a.cell_start[row + x0];
             ms1 = a.cell_start[row + x1 + 1];
         }
-        const int cnt = min(64, nrows - rbase);
-        auto tail = [&](uint32_t s0, uint32_t s1) {
-            for (uint32_t sb = s0 + 64; sb < s1; sb += 64) {
-                const uint32_t s = sb + lane;
-                const bool v = s < s1;
-                f(v ? a.spts[s] : zero, v, s);
-            }
-        };
-        int i = 0;
-        for (; i + 7 < cnt; i += 8) {
-            uint32_t b[8], e[8];
-            bool v[8];
-            float4 p[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                b[j] = __builtin_amdgcn_readlane(ms0, i + j);
-                e[j] = __builtin_amdgcn_readlane(ms1, i + j);
-                v[j] = b[j] + lane < e[j];
-                p[j] = v[j] ? a.spts[b[j] + lane] : zero;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f(p[j], v[j], b[j] + lane);
-                tail(b[j], e[j]);
-            }
+        const uint32_t len = ms1 - ms0;
+        uint32_t incl = len;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
         }
-        for (; i < cnt; ++i) {
-            const uint32_t b0 = __builtin_amdgcn_readlane(ms0, i), e0 = __builtin_amdgcn_readlane(ms1, i);
-            const bool v0 = b0 + lane < e0;
-            f(v0 ? a.spts[b0 + lane] : zero, v0, b0 + lane);
-            tail(b0, e0);
+        const uint32_t pre = incl - len;  // list position of this lane's row
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        for (uint32_t t0 = 0; t0 < total; t0 += 4 * 64) {
+            uint32_t slot[4];
+            bool v[4];
+            float4 p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = t0 + j * 64 + lane;
+                int lo = 0;  // the last row whose list position is <= t (empty rows share theirs)
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const uint32_t pc = __shfl(pre, lo + step, 64);
+                    if (pc <= t) lo += step;
+                }
+                slot[j] = __shfl(ms0, lo, 64) + (t - __shfl(pre, lo, 64));
+                v[j] = t < total;
+                p[j] = v[j] ? a.spts[slot[j]] : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (t0 + j * 64 < total) f(p[j], v[j], slot[j]);
         }
     }
 }
@@ -981,23 +981,72 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
                 re[i] = a.cell_start[row + x1 + 1];
             }
         }
-        // the ranges read as one list: start[i] = list position of row i, off[i] maps a list
-        // position inside row i to its sorted slot
-        uint32_t off[9], start[9], total_pts = 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            start[i] = total_pts;
-            off[i] = rb[i] - total_pts;
-            total_pts += re[i] - rb[i];
-        }
         // A crowded cube (a dense spot of the cloud) goes to the wave-per-query kernel, flagged
         // so that that kernel starts with this same cube.
-        const bool diverted = qvalid && total_pts > a.heavy && a.fail_list != nullptr;
-        if (diverted) total_pts = 0;
+        uint32_t cube_pts = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cube_pts += re[i] - rb[i];
+        const bool diverted = qvalid && cube_pts > a.heavy && a.fail_list != nullptr;
 
         uint64_t best = PCRS_EMPTY_KEY;
         float best_d2 = __builtin_inff();
         const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto visit = [&](const float4 &p) {
+            const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+            if (d2 <= best_d2) {
+                const uint64_t k = make_key(d2, __float_as_uint(p.w));
+                if (k < best) {
+                    best = k;
+                    best_d2 = d2;
+                }
+            }
+        };
+        auto share = [&]() {  // the best key of the query's eight lanes, in all of them
+#pragma unroll
+            for (int r = 1; r < NN_SUB; r <<= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)best, r, 64);
+                const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), r, 64);
+                const uint64_t other = ((uint64_t)hi << 32) | lo;
+                if (other < best) best = other;
+            }
+            best_d2 = key_d2(best);
+        };
+        // The query's own row first (rows are indexed 3 (dz + 1) + (dy + 1): the centre is 4).
+        // Where the cloud is dense the nearest neighbour is almost always there, and every
+        // other row lies farther away than it in y and z alone.
+        const uint32_t n_centre = diverted ? 0u : re[4] - rb[4];
+        for (uint32_t t0 = sub; t0 < n_centre; t0 += 4 * NN_SUB) {
+            float4 p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = t0 + j * NN_SUB;
+                p[j] = (t < n_centre) ? a.spts[rb[4] + t] : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (t0 + j * NN_SUB < n_centre) visit(p[j]);
+        }
+        share();
+        // The other rows as one list, without those that cannot hold anything nearer: the gap to
+        // a row is at least the gap to the faces of the query's own cell in y and z, shortened by
+        // the same allowance for f32 cell assignment as the certification below.  A row at exactly
+        // the best distance stays (ties go to the larger index, wherever it lies).
+        const float amax_q = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+        const float allow = g.slack + 2e-6f * amax_q;
+        const float gy[3] = {fmaxf(uy - (float)cy * g.cell - allow, 0.0f), 0.0f,
+                             fmaxf((float)(cy + 1) * g.cell - uy - allow, 0.0f)};
+        const float gz[3] = {fmaxf(uz - (float)cz * g.cell - allow, 0.0f), 0.0f,
+                             fmaxf((float)(cz + 1) * g.cell - uz - allow, 0.0f)};
+        // start[i] = list position of row i, off[i] maps a list position inside row i to its slot
+        uint32_t off[9], start[9], total_pts = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float gap2 = (gy[i % 3] * gy[i % 3] + gz[i / 3] * gz[i / 3]) * (1.0f - 8e-6f);
+            const bool skip = i == 4 || diverted || gap2 > best_d2;
+            start[i] = total_pts;
+            off[i] = rb[i] - total_pts;
+            total_pts += skip ? 0u : re[i] - rb[i];
+        }
         for (uint32_t t0 = sub; t0 < total_pts; t0 += 4 * NN_SUB) {
             float4 p[4];
 #pragma unroll
@@ -1009,27 +1058,10 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
                 p[j] = (t < total_pts) ? a.spts[t + o] : zero;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (t0 + j * NN_SUB < total_pts) {
-                    const float d2 = sqdist(qx, qy, qz, p[j].x, p[j].y, p[j].z);
-                    if (d2 <= best_d2) {
-                        const uint64_t k = make_key(d2, __float_as_uint(p[j].w));
-                        if (k < best) {
-                            best = k;
-                            best_d2 = d2;
-                        }
-                    }
-                }
-            }
+            for (int j = 0; j < 4; ++j)
+                if (t0 + j * NN_SUB < total_pts) visit(p[j]);
         }
-#pragma unroll
-        for (int r = 1; r < NN_SUB; r <<= 1) {
-            const uint32_t lo = __shfl_xor((uint32_t)best, r, 64);
-            const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), r, 64);
-            const uint64_t other = ((uint64_t)hi << 32) | lo;
-            if (other < best) best = other;
-        }
-        best_d2 = key_d2(best);
+        share();
         if (sub != 0 || !active) continue;  // after the shuffles: one lane finishes the query
         if (!qvalid) {
             out.nn_idx[qi] = PCRS_NO_INDEX;

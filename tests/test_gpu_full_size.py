@@ -1,0 +1,80 @@
+"""The 100 M-point tile (an aerial-LiDAR shaped slab, [0, 500)^2 x [0, 20)) on one GPU, checked
+through properties that do not need a whole-cloud CPU run: a sample of the means against the
+brute-force kernel (an independent code path: an LDS-tiled scan over all points), the threshold
+against the oracle's sequential sums over the device's means, the mask against the threshold,
+and the normals against an f64 eigen-decomposition of the sampled neighbourhoods."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.mark.timeout(600)
+def test_100m_tile_properties(oracle):
+    import torch
+
+    from pointclouds_rs import _ffi, synth
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine(0)
+    n, k = 100_000_000, 16
+    scale = (F(500.0), F(500.0), F(20.0))
+    cols = [eng.from_numpy((synth.uniform01(9, n, a) * scale[a]).astype(F)) for a in range(3)]
+    vp = (250.0, 250.0, 1000.0)  # the sensor above the tile
+    mean = eng.empty(n); nx = eng.empty(n); ny = eng.empty(n); nz = eng.empty(n)
+    keep = eng.empty(n, "uint8")
+    ix = eng.build_index(*cols, k + 1)
+    eng.sor_normals_range(ix, 0, n, k, k, vp, mean, nx, ny, nz)
+    thr, ok, n_keep = eng.select(mean, 1.0, mean, keep)
+    stages = eng.index_stats(ix)
+    eng.destroy_index(ix)
+    assert ok and sum(stages) == n and stages[2] == 0
+
+    # threshold: the reference's sequential f32 sums over these very means (host, one thread)
+    mean_h = mean.cpu().numpy()
+    ok_ref, thr_ref, _, _ = oracle.sor_threshold(mean_h, 1.0)
+    assert ok_ref and F(thr).view(np.uint32) == F(thr_ref).view(np.uint32)
+    # mask: exactly the means at or below the threshold
+    assert n_keep == int((mean <= thr).sum().item())
+    assert bool(((mean <= thr) == (keep != 0)).all().item())
+    # normals: unit length, turned toward the viewpoint
+    ln = nx * nx + ny * ny + nz * nz
+    assert float((ln - 1.0).abs().max().item()) <= 1e-5
+    toward = nx * (vp[0] - cols[0]) + ny * (vp[1] - cols[1]) + nz * (vp[2] - cols[2])
+    assert float(toward.min().item()) >= -1e-3
+
+    # a sample of queries against the brute-force kernel
+    ns = 768
+    rng = np.random.default_rng(1)
+    sample = np.sort(rng.choice(n, size=ns, replace=False))
+    st = torch.from_numpy(sample).to(eng.device)
+    q = [c[st].contiguous() for c in cols]
+    bf = C.c_void_p()
+    eng.ctx.check(eng.lib.pcrs_index_build_dev(eng.ctx.handle, *[eng._p(c) for c in cols], n, k + 1,
+                                               _ffi.ALGO_BRUTE, C.byref(bf)))
+    idx = eng.empty(ns * (k + 1), "int32"); dist = eng.empty(ns * (k + 1)); cnt = eng.empty(ns, "int32")
+    eng.ctx.check(eng.lib.pcrs_knn_batch_dev(bf, *[eng._p(c) for c in q], ns, k + 1, eng._p(idx),
+                                             eng._p(dist), eng._p(cnt)))
+    torch.cuda.synchronize()
+    eng.lib.pcrs_index_destroy(bf)
+    d = dist.cpu().numpy().reshape(ns, k + 1)
+    s = np.zeros(ns, dtype=F)
+    for j in range(1, k + 1):  # rank 0 is the query itself (statistical_outlier.rs:28-37)
+        s = (s + d[:, j]).astype(F)
+    ref = (s / F(k)).astype(F)
+    assert np.array_equal(mean_h[sample].view(np.uint32), ref.view(np.uint32))
+    # normals of the sample: smallest eigenvector of the covariance of the k nearest (self included)
+    nb = idx.cpu().numpy().view(np.uint32).reshape(ns, k + 1)[:, :k].astype(np.int64)
+    nbt = torch.from_numpy(nb.reshape(-1)).to(eng.device)
+    P = np.stack([c[nbt].cpu().numpy().reshape(ns, k).astype(np.float64) for c in cols], axis=2)
+    Pc = P - P.mean(axis=1, keepdims=True)
+    cov = np.einsum("nki,nkj->nij", Pc, Pc)
+    w, v = np.linalg.eigh(cov)
+    got = np.stack([t[st].cpu().numpy().astype(np.float64) for t in (nx, ny, nz)], axis=1)
+    clear = (w[:, 1] - w[:, 0]) > 1e-3 * w[:, 2]  # a well separated smallest eigenvalue
+    assert clear.sum() > ns // 2
+    cosang = np.abs(np.einsum("ni,ni->n", got, v[:, :, 0]))
+    assert cosang[clear].min() >= 1.0 - 1e-6

@@ -397,6 +397,15 @@ struct CellArgs {
     uint32_t kcollect;      // neighbours whose identity is needed (pass 2), 0 = none
 };
 
+// Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Queries come in
+// cell order, so consecutive blocks read neighbouring rows of the sorted array: this bijection
+// hands every XCD one contiguous eighth of the blocks, and the rows a block shares with the
+// blocks one row or one layer of cells away are found in its own XCD's L2.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nblocks) {
+    const uint32_t q = nblocks / 8u, r = nblocks % 8u, x = b % 8u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + b / 8u;
+}
+
 // Calls f(point, address of the point in the sorted array) for every point of the (2R+1)^3 cube
 // of cells centred on (cx, cy, cz).
 template <class F>
@@ -453,8 +462,8 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
     if (a.qmode >= 2) total = *a.qcount;
     const GridGeom &g = a.g;
 
-    for (uint32_t pos = blockIdx.x * GB_THREADS + threadIdx.x; pos < total;
-         pos += gridDim.x * GB_THREADS) {
+    for (uint32_t pos = xcd_contiguous_block(blockIdx.x, gridDim.x) * GB_THREADS + threadIdx.x;
+         pos < total; pos += gridDim.x * GB_THREADS) {
         uint32_t qi;
         float qx, qy, qz;
         if (a.qmode == 0 || a.qmode == 3) {
@@ -549,7 +558,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
                     if ((uint32_t)i >= first && (uint32_t)i < c) sum += sqrtf(D[i]);
                 mean = sum / (float)(c - first);
             }
-            out.mean[qi] = mean;
+            store_mean(out, qi, mean);
         }
 
         if constexpr (COLLECT) {
@@ -863,7 +872,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
                         if ((uint32_t)i >= first && (uint32_t)i < c) sum += sqrtf(D[i]);
                     mean = sum / (float)(c - first);
                 }
-                out.mean[qi] = mean;
+                store_mean(out, qi, mean);
             }
             if (COLLECT) {
                 KnnOut o2 = out;
@@ -1176,19 +1185,20 @@ __global__ __launch_bounds__(GB_THREADS) void unpack_sorted_kernel(const float4 
 // Second half of the normal estimation: one thread per query turns the covariance sums left by
 // the search kernels into the oriented unit normal.
 __global__ __launch_bounds__(GB_THREADS) void normals_from_cov_kernel(
-    uint32_t nq, const float *cov, size_t stride, const float *qx, const float *qy,
-    const float *qz, KnnOut out) {
+    uint32_t nq, const float *rec, const float *qx, const float *qy, const float *qz, KnnOut out) {
     const uint32_t qi = blockIdx.x * GB_THREADS + threadIdx.x;
     if (qi >= nq) return;
+    const float4 r0 = *reinterpret_cast<const float4 *>(rec + (size_t)qi * PCRS_REC_FLOATS);
+    const float4 r1 = *reinterpret_cast<const float4 *>(rec + (size_t)qi * PCRS_REC_FLOATS + 4);
     float nnx = 0.0f, nny = 0.0f, nnz = 1.0f;
-    const float c00 = cov[qi];
+    const float c00 = r0.x;
     if (c00 >= 0.0f || c00 != c00)
-        normal_from_cov(c00, cov[stride + qi], cov[2 * stride + qi], cov[3 * stride + qi],
-                        cov[4 * stride + qi], cov[5 * stride + qi], qx[qi], qy[qi], qz[qi], out.vp,
-                        nnx, nny, nnz);
+        normal_from_cov(c00, r0.y, r0.z, r0.w, r1.x, r1.y, qx[qi], qy[qi], qz[qi], out.vp, nnx,
+                        nny, nnz);
     out.nx[qi] = nnx;
     out.ny[qi] = nny;
     out.nz[qi] = nnz;
+    if (out.mean) out.mean[qi] = r1.z;
 }
 
 }  // namespace pcrs
@@ -1725,9 +1735,8 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     // normals: the search kernels leave covariance sums, a light kernel solves them afterwards
     DevBuf cov;
     if (out.nx && !out.cov) {
-        PCRS_HIP_CHECK(ctx, cov.alloc(ctx, 6 * (size_t)nq * sizeof(float)));
+        PCRS_HIP_CHECK(ctx, cov.alloc(ctx, PCRS_REC_FLOATS * (size_t)nq * sizeof(float)));
         out.cov = cov.as<float>();
-        out.cov_stride = nq;
     }
     // the timing bracket covers the dominant kernel only (stage 1 over every query), so that it
     // can be set against the same kernel's duration in a profiler trace
@@ -1785,7 +1794,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         const float *cqy = q.self ? ix->y + q.out_offset : q.qy;
         const float *cqz = q.self ? ix->z + q.out_offset : q.qz;
         hipLaunchKernelGGL(normals_from_cov_kernel, dim3((nq + GB_THREADS - 1) / GB_THREADS),
-                           dim3(GB_THREADS), 0, ctx->stream, nq, cov.as<float>(), (size_t)nq, cqx,
+                           dim3(GB_THREADS), 0, ctx->stream, nq, cov.as<float>(), cqx,
                            cqy, cqz, out);
     }
     ctx->timing = timing_was;

@@ -297,6 +297,19 @@ __device__ __forceinline__ void normal_from_cov(float c00, float c01, float c02,
 // Per-query consumers.  `cnt` = valid neighbours available (ascending), `qvalid` = finite query,
 // `qo` = output slot; neighbour coordinates come from the accessor's fetch().
 // COV_ONLY promises that o.cov is set whenever o.nx is, and leaves the solver out of the kernel.
+// While the normals are pending, a query's results live in one 32-byte record of o.cov
+// ({c00, c01, c02, c11, c12, c22, SOR mean, unused}): the search kernels answer queries in cell
+// order, so anything they write per query is scattered over the output, and a whole 32-byte
+// sector per query costs a fraction of seven separate 4-byte stores.  normals_from_cov_kernel
+// reads the records in index order and writes the caller's columns coalesced.
+constexpr size_t PCRS_REC_FLOATS = 8;
+__device__ __forceinline__ void store_mean(const KnnOut &o, size_t qo, float mean) {
+    if (o.cov)
+        o.cov[qo * PCRS_REC_FLOATS + 6] = mean;
+    else
+        o.mean[qo] = mean;
+}
+
 template <bool COV_ONLY = false, class Nbrs>
 __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvalid, size_t qo,
                                         float qx, float qy, float qz, const KnnOut &o) {
@@ -340,7 +353,7 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
                 mean = sum / (float)nn;
             }
         }
-        o.mean[qo] = mean;
+        store_mean(o, qo, mean);
     }
     if (o.nx) {
         // estimate.rs:45-109
@@ -374,18 +387,15 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
                 c22 += dz * dz;
             });
             if (COV_ONLY || o.cov) {  // the eigenvector is solved by normals_from_cov_kernel
-                o.cov[qo] = c00;
-                o.cov[o.cov_stride + qo] = c01;
-                o.cov[2 * o.cov_stride + qo] = c02;
-                o.cov[3 * o.cov_stride + qo] = c11;
-                o.cov[4 * o.cov_stride + qo] = c12;
-                o.cov[5 * o.cov_stride + qo] = c22;
+                float *rec = o.cov + qo * PCRS_REC_FLOATS;
+                *reinterpret_cast<float4 *>(rec) = make_float4(c00, c01, c02, c11);
+                *reinterpret_cast<float2 *>(rec + 4) = make_float2(c12, c22);
                 return;
             }
             if constexpr (!COV_ONLY)
                 normal_from_cov(c00, c01, c02, c11, c12, c22, qx, qy, qz, o.vp, nnx, nny, nnz);
         } else if (COV_ONLY || o.cov) {
-            o.cov[qo] = -1.0f;  // no neighbours (a variance is never negative)
+            o.cov[qo * PCRS_REC_FLOATS] = -1.0f;  // no neighbours (a variance is never negative)
             return;
         }
         o.nx[qo] = nnx;

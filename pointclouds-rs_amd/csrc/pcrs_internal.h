@@ -152,11 +152,10 @@ struct KnnOut {
     float *nx = nullptr, *ny = nullptr, *nz = nullptr;  // [nq]
     uint32_t k_nrm = 0;
     float vp[3] = {0, 0, 0};
-    // When set, the consumers store the six covariance sums (columns of cov_stride floats,
-    // c00 = -1 for "no neighbours") instead of solving for the normal: the f64 eigen solver needs
-    // ~120 registers and would cap the occupancy of the search kernels.
+    // When set, the consumers store the six covariance sums and the SOR mean in a record of eight
+    // floats per query (c00 = -1 for "no neighbours") instead of solving for the normal: the f64
+    // eigen solver needs ~120 registers and would cap the occupancy of the search kernels.
     float *cov = nullptr;
-    size_t cov_stride = 0;
     // 1-NN correspondence
     uint32_t *nn_idx = nullptr;  // [nq]
     float *nn_d2 = nullptr;      // [nq] squared distance, +inf when none

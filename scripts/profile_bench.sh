@@ -1,7 +1,8 @@
 #!/bin/bash
 # Profiles `bench.py` on the GPU box: one kernel trace and separate counter passes (rocprofv3
 # cannot split counters over passes itself).  Results land under gpurun_out/prof_<tag>/ and are
-# folded into profiles/ by scripts/fold_profiles.py.
+# folded into profiles/ by scripts/fold_profiles.py.  Delete the local gpurun_out/prof_<tag>/ of an
+# earlier run first: results merge into it, and the fold would average old and new launches.
 set -o pipefail
 tag=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

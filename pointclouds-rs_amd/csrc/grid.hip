@@ -544,6 +544,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
         }
 
         // ---- SOR mean straight from the sorted distances (statistical_outlier.rs:28-37)
+        KnnOut o2 = out;
         if (out.mean) {
             const uint32_t kk = out.k_sor + 1u;
             uint32_t c = 0;
@@ -558,7 +559,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
                     if ((uint32_t)i >= first && (uint32_t)i < c) sum += sqrtf(D[i]);
                 mean = sum / (float)(c - first);
             }
-            store_mean(out, qi, mean);
+            store_mean(o2, qi, mean);
         }
 
         if constexpr (COLLECT) {
@@ -633,8 +634,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
                     ord[i][threadIdx.x] = (uint8_t)oj;
                 }
             }
-            KnnOut o2 = out;
-            o2.mean = nullptr;  // already written from D[]
+            o2.mean = nullptr;  // already found from D[]
             const uint32_t have = hits < a.kcollect ? hits : a.kcollect;
             consume<true>(LdsNbrs<CAP, GB_THREADS>(lst, ord, a.spts, qx, qy, qz), have, true,
                           (size_t)qi, qx, qy, qz, o2);
@@ -857,6 +857,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             continue;
         }
         if (lane == 0) {
+            KnnOut o2 = out;
             if (out.mean) {
                 const uint32_t kk = out.k_sor + 1u;
                 uint32_t c = 0;
@@ -872,10 +873,9 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
                         if ((uint32_t)i >= first && (uint32_t)i < c) sum += sqrtf(D[i]);
                     mean = sum / (float)(c - first);
                 }
-                store_mean(out, qi, mean);
+                store_mean(o2, qi, mean);
             }
             if (COLLECT) {
-                KnnOut o2 = out;
                 o2.mean = nullptr;
                 consume(ListNbrs{&wl_key[w][0], a.rx, a.ry, a.rz}, have, true, (size_t)qi, qx, qy,
                         qz, o2);

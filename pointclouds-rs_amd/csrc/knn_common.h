@@ -303,9 +303,11 @@ __device__ __forceinline__ void normal_from_cov(float c00, float c01, float c02,
 // sector per query costs a fraction of seven separate 4-byte stores.  normals_from_cov_kernel
 // reads the records in index order and writes the caller's columns coalesced.
 constexpr size_t PCRS_REC_FLOATS = 8;
-__device__ __forceinline__ void store_mean(const KnnOut &o, size_t qo, float mean) {
+// A mean found before the record is written travels in the caller's copy of KnnOut
+// (rec_mean) and leaves with the record: two 16-byte stores fill the sector at once.
+__device__ __forceinline__ void store_mean(KnnOut &o, size_t qo, float mean) {
     if (o.cov)
-        o.cov[qo * PCRS_REC_FLOATS + 6] = mean;
+        o.rec_mean = mean;
     else
         o.mean[qo] = mean;
 }
@@ -314,6 +316,7 @@ template <bool COV_ONLY = false, class Nbrs>
 __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvalid, size_t qo,
                                         float qx, float qy, float qz, const KnnOut &o) {
     if (!qvalid) cnt = 0;
+    float rec_mean = o.rec_mean;
     if (o.idx || o.dist || o.count) {
         const uint32_t c = cnt < o.k ? cnt : o.k;
         if (o.count) o.count[qo] = c;
@@ -353,7 +356,10 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
                 mean = sum / (float)nn;
             }
         }
-        store_mean(o, qo, mean);
+        if (o.cov)
+            rec_mean = mean;
+        else
+            o.mean[qo] = mean;
     }
     if (o.nx) {
         // estimate.rs:45-109
@@ -387,15 +393,18 @@ __device__ __forceinline__ void consume(const Nbrs &nb, uint32_t cnt, bool qvali
                 c22 += dz * dz;
             });
             if (COV_ONLY || o.cov) {  // the eigenvector is solved by normals_from_cov_kernel
-                float *rec = o.cov + qo * PCRS_REC_FLOATS;
-                *reinterpret_cast<float4 *>(rec) = make_float4(c00, c01, c02, c11);
-                *reinterpret_cast<float2 *>(rec + 4) = make_float2(c12, c22);
+                float4 *rec = reinterpret_cast<float4 *>(o.cov + qo * PCRS_REC_FLOATS);
+                rec[0] = make_float4(c00, c01, c02, c11);
+                rec[1] = make_float4(c12, c22, rec_mean, 0.0f);
                 return;
             }
             if constexpr (!COV_ONLY)
                 normal_from_cov(c00, c01, c02, c11, c12, c22, qx, qy, qz, o.vp, nnx, nny, nnz);
         } else if (COV_ONLY || o.cov) {
-            o.cov[qo * PCRS_REC_FLOATS] = -1.0f;  // no neighbours (a variance is never negative)
+            // no neighbours (a variance is never negative)
+            float4 *rec = reinterpret_cast<float4 *>(o.cov + qo * PCRS_REC_FLOATS);
+            rec[0] = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+            rec[1] = make_float4(0.0f, 0.0f, rec_mean, 0.0f);
             return;
         }
         o.nx[qo] = nnx;

@@ -156,6 +156,7 @@ struct KnnOut {
     // floats per query (c00 = -1 for "no neighbours") instead of solving for the normal: the f64
     // eigen solver needs ~120 registers and would cap the occupancy of the search kernels.
     float *cov = nullptr;
+    float rec_mean = 0.0f;  // per-thread: the query's mean on its way into the record
     // 1-NN correspondence
     uint32_t *nn_idx = nullptr;  // [nq]
     float *nn_d2 = nullptr;      // [nq] squared distance, +inf when none

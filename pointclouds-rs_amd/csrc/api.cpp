@@ -834,7 +834,7 @@ int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, flo
     PCRS_TRY(pcrs_ctx_pinned(ctx, sb + 64, &pin));
     PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb));
     PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount));
-    PCRS_TRY(download(ctx, pin, sc, sb + 64));
+    PCRS_TRY(pcrs_launch_publish(ctx, sc, pin, sb + 64));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     float t;
     int ok;

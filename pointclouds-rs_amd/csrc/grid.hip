@@ -1332,15 +1332,12 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
 
     // 1. bounding box of the finite points
     const unsigned nb = grid_for(ctx, m, GB_THREADS);
-    DevBuf partials;
-    PCRS_HIP_CHECK(ctx, partials.alloc(ctx, nb * sizeof(BBoxPartial)));
-    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
-                       ix->z, m, partials.as<BBoxPartial>());
+    // (the blocks write their partial boxes straight into pinned host memory: no copy command)
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, nb * sizeof(BBoxPartial) + 64, &pin));
     BBoxPartial *hp = reinterpret_cast<BBoxPartial *>(pin);
-    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hp, partials.p, nb * sizeof(BBoxPartial),
-                                       hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
+                       ix->z, m, hp);
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     size_t nvalid = 0;
@@ -1418,8 +1415,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         }
         sorted_done = two_level;
         if (attempt == 3 || fixed_cell) break;
-        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_nonempty, d_nonempty, sizeof(uint32_t),
-                                           hipMemcpyDeviceToHost, ctx->stream));
+        PCRS_TRY(pcrs_launch_publish(ctx, d_nonempty, h_nonempty, sizeof(uint32_t)));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t nonempty = *h_nonempty;
         const double occ = (double)nvalid / (double)(nonempty ? nonempty : 1);

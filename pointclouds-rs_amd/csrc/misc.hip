@@ -282,6 +282,23 @@ __global__ __launch_bounds__(256) void scatter_perm_kernel(const float *in, cons
     if (i < n) out[perm[i]] = in[i];
 }
 
+// A few words from device memory straight into pinned host memory: a kernel of one wave costs
+// less than a copy command, and the host then only waits for the stream.
+__global__ void publish_words_kernel(const uint32_t *src, uint32_t *host_dst, uint32_t nwords) {
+    for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) host_dst[i] = src[i];
+}
+
+int pcrs_launch_publish(pcrs_ctx *ctx, const void *d_src, void *pinned_dst, size_t bytes) {
+    if (bytes == 0) return PCRS_OK;
+    if (bytes % 4 || bytes > 65536)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "publish: a small multiple of 4 bytes");
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       reinterpret_cast<const uint32_t *>(d_src),
+                       reinterpret_cast<uint32_t *>(pinned_dst), (uint32_t)(bytes / 4));
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
 int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *perm, size_t n,
                              float *out) {
     if (n == 0) return PCRS_OK;

@@ -243,6 +243,9 @@ int pcrs_launch_invalid_defaults(pcrs_ctx *ctx, const float *rx, const float *ry
 int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint8_t *keep,
                      unsigned long long *d_count);
 // out[perm[i]] = in[i]
+// Copies a few words (a multiple of 4 bytes, at most 64 KB) from device memory into pinned host
+// memory with a one-wave kernel; visible to the host after the stream has been synchronised.
+int pcrs_launch_publish(pcrs_ctx *ctx, const void *d_src, void *pinned_dst, size_t bytes);
 int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *perm, size_t n,
                              float *out);
 int pcrs_launch_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,

@@ -1408,7 +1408,7 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
             PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));  // icp.rs:186
         }
         iter += nb;
-        PCRS_TRY(download(ctx, hs, ds, sizeof(*hs)));
+        PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));  // hs is pinned
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done) break;
     }

@@ -418,10 +418,6 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
     const int lane = threadIdx.x;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
     float s = chunk_begin ? sc->run : 0.0f;  // uniform across the wave
-#ifdef PCRS_STATS_DEBUG
-    uint32_t dbg_fallbacks = 0, dbg_rounds = 0, dbg_whole = 0;
-    long long dbg_t_fb = 0, dbg_t0 = wall_clock64();
-#endif
     // the composites of the next batch are requested while the current one is being scanned
     auto load_batch = [&](uint32_t base, Composite (&dst)[G][W]) {
 #pragma unroll
@@ -493,9 +489,6 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
             // the sum only grows: in the binade after the batch = in the binade throughout
             if (inc < ST_SAT && S + inc < (1u << 24)) {
                 s = __uint_as_float((bits & 0xFF800000u) | ((S + inc) & 0x7FFFFFu));
-#ifdef PCRS_STATS_DEBUG
-                ++dbg_whole;
-#endif
                 continue;
             }
         }
@@ -577,17 +570,6 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                 s = __uint_as_float((bits & 0xFF800000u) | (Sj & 0x7FFFFFu));
             }
             if (first_bad < lim) {
-#ifdef PCRS_STATS_DEBUG
-                ++dbg_fallbacks;
-                const long long dbg_f0 = wall_clock64();
-                if (lane == 0 && dbg_fallbacks <= 0)
-                    printf("pass %d fallback %u: chunk %u e_now %d built for %d %d %d %d\n", PASS,
-                           dbg_fallbacks, base + first_bad, e_now,
-                           comp[(size_t)(base + first_bad) * W].e,
-                           W > 1 ? comp[(size_t)(base + first_bad) * W + 1].e : 0,
-                           W > 2 ? comp[(size_t)(base + first_bad) * W + 2].e : 0,
-                           W > 3 ? comp[(size_t)(base + first_bad) * W + 3].e : 0);
-#endif
                 // element-by-element f32 adds over this chunk (lane-major element order)
                 const uint32_t bad_chunk = base + first_bad;
                 const float4 mine4 = load_elements(bad_chunk);
@@ -604,21 +586,10 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                     s = s + x.w;
                 }
                 __builtin_amdgcn_wave_barrier();
-#ifdef PCRS_STATS_DEBUG
-                dbg_t_fb += wall_clock64() - dbg_f0;
-#endif
             }
-#ifdef PCRS_STATS_DEBUG
-            ++dbg_rounds;
-#endif
             pos = first_bad + 1;
         }
     }
-#ifdef PCRS_STATS_DEBUG
-    if (lane == 0)
-        printf("pass %d: %u element-wise chunks of %u, %u rounds, %u whole batches, final s %g; ticks total %lld fallback %lld\n",
-               PASS, dbg_fallbacks, nchunks, dbg_rounds, dbg_whole, s, wall_clock64() - dbg_t0, dbg_t_fb);
-#endif
     if (lane == 0) sc->run = s;
     if (lane == 0 && last) {
         const float nn = (float)sc->nf;  // finite_dists.len() as f32

@@ -78,3 +78,62 @@ def test_100m_tile_properties(oracle):
     assert clear.sum() > ns // 2
     cosang = np.abs(np.einsum("ni,ni->n", got, v[:, :, 0]))
     assert cosang[clear].min() >= 1.0 - 1e-6
+
+
+@pytest.mark.timeout(600)
+def test_clustered_3m_sampled_parity():
+    """Three million points of very uneven density (two tight blobs inside a sparse box): the
+    sort's buckets overflow their staging array, crowded cubes go to the wave-per-query kernel,
+    and the cell size is re-aimed several times.  A sample of means against the brute-force
+    kernel, and the runs of cells must still partition the cloud."""
+    import torch
+
+    from pointclouds_rs import _ffi
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine(0)
+    rng = np.random.default_rng(5)
+    n, k = 3_000_000, 16
+    pts = np.concatenate([
+        rng.normal((10.0, 10.0, 10.0), 0.05, (1_500_000, 3)),
+        rng.normal((60.0, 20.0, 5.0), 0.5, (1_000_000, 3)),
+        rng.uniform(0.0, 100.0, (500_000, 3)),
+    ]).astype(F)
+    pts = pts[rng.permutation(n)]
+    cols = [eng.from_numpy(np.ascontiguousarray(pts[:, a])) for a in range(3)]
+    mean = eng.empty(n); nx = eng.empty(n); ny = eng.empty(n); nz = eng.empty(n)
+    ix = eng.build_index(*cols, k + 1)
+    eng.sor_normals_range(ix, 0, n, k, k, (0.0, 0.0, 0.0), mean, nx, ny, nz)
+    stages = eng.index_stats(ix)
+    bounds = eng.slot_bounds(ix, 8)
+    assert sum(stages) == n
+    assert bounds[0] == 0 and bounds[-1] == n and bounds == sorted(bounds)
+    seen = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    for r in range(8):
+        c = bounds[r + 1] - bounds[r]
+        point = eng.empty(c, "int32")
+        eng.sor_normals_slots(ix, bounds[r], c, 0, 0, (0.0, 0.0, 0.0), point, None, None, None, None)
+        seen.index_add_(0, point.to(torch.int64), torch.ones(c, dtype=torch.int32, device=eng.device))
+    assert bool((seen == 1).all().item())
+    eng.destroy_index(ix)
+
+    ns = 1024
+    sample = np.sort(rng.choice(n, size=ns, replace=False))
+    st = torch.from_numpy(sample).to(eng.device)
+    q = [c[st].contiguous() for c in cols]
+    bf = C.c_void_p()
+    eng.ctx.check(eng.lib.pcrs_index_build_dev(eng.ctx.handle, *[eng._p(c) for c in cols], n, k + 1,
+                                               _ffi.ALGO_BRUTE, C.byref(bf)))
+    idx = eng.empty(ns * (k + 1), "int32"); dist = eng.empty(ns * (k + 1)); cnt = eng.empty(ns, "int32")
+    eng.ctx.check(eng.lib.pcrs_knn_batch_dev(bf, *[eng._p(c) for c in q], ns, k + 1, eng._p(idx),
+                                             eng._p(dist), eng._p(cnt)))
+    torch.cuda.synchronize()
+    eng.lib.pcrs_index_destroy(bf)
+    d = dist.cpu().numpy().reshape(ns, k + 1)
+    s = np.zeros(ns, dtype=F)
+    for j in range(1, k + 1):
+        s = (s + d[:, j]).astype(F)
+    ref = (s / F(k)).astype(F)
+    assert np.array_equal(mean.cpu().numpy()[sample].view(np.uint32), ref.view(np.uint32))
+    ln = nx * nx + ny * ny + nz * nz
+    assert float((ln - 1.0).abs().max().item()) <= 1e-5

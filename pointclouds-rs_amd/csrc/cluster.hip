@@ -30,18 +30,19 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
     }
 }
 
-__device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
+// joins the sets of a and b; returns the root of the joined set as seen by this thread
+__device__ __forceinline__ uint32_t uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
     for (;;) {
         a = uf_find(parent, a);
         b = uf_find(parent, b);
-        if (a == b) return;
+        if (a == b) return a;
         if (a < b) {
             const uint32_t t = a;
             a = b;
             b = t;
         }
         // the larger root goes under the smaller one; a lost race starts over
-        if (atomicCAS(parent + a, a, b) == a) return;
+        if (atomicCAS(parent + a, a, b) == a) return b;
     }
 }
 
@@ -95,11 +96,38 @@ __global__ __launch_bounds__(256) void cluster_union_kernel(
     const uint32_t a = order[i];
     const float ax = x[a], ay = y[a], az = z[a];
     const long long cx = ux[cell], cy = uy[cell], cz = uz[cell];
+    // In a dense cluster nearly every pair is already joined when it is looked at, and a find
+    // is a chain of dependent device-scope loads.  The thread therefore remembers the root of its
+    // own point and first reads the neighbour's parent with a plain load, four neighbours at a
+    // time: parent[b] == root, even read from a stale line, proves that b and the root were once
+    // in one set — sets only ever merge — so the pair needs no union.
+    uint32_t root = a;
     auto join_range = [&](uint32_t from, uint32_t to) {
-        for (uint32_t j = from; j < to; ++j) {
-            const uint32_t b = order[j];
-            const float dx = ax - x[b], dy = ay - y[b], dz = az - z[b];
-            if ((dx * dx + dy * dy) + dz * dz <= r2) uf_union(parent, a, b);  // :151-153
+        if (to - from < 4u) {  // sparse cells: nothing to batch
+            for (uint32_t j = from; j < to; ++j) {
+                const uint32_t b = order[j];
+                const float dx = ax - x[b], dy = ay - y[b], dz = az - z[b];
+                if ((dx * dx + dy * dy) + dz * dz <= r2 && b != root)
+                    root = uf_union(parent, a, b);
+            }
+            return;
+        }
+        for (uint32_t j0 = from; j0 < to; j0 += 4) {
+            uint32_t b[4], pb[4];
+            float d2[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t j = j0 + t < to ? j0 + t : to - 1;
+                b[t] = order[j];
+                const float dx = ax - x[b[t]], dy = ay - y[b[t]], dz = az - z[b[t]];
+                d2[t] = (dx * dx + dy * dy) + dz * dz;
+                pb[t] = parent[b[t]];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (j0 + t < to && d2[t] <= r2 && pb[t] != root && b[t] != root)
+                    root = uf_union(parent, a, b[t]);  // :151-153
+            }
         }
     };
     // own cell: the points after this one (:148)

@@ -390,6 +390,8 @@ struct CellArgs {
     int wave_radii[5];      // cube half-widths the wave-per-query kernel tries in turn; entry 0
                             // is only for queries flagged PCRS_HEAVY_FLAG in the list
     int n_radii;            // entries of wave_radii in use
+    uint32_t all_gate;      // the fifth radius (the whole grid) only when at most this many
+                            // queries entered the launch
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
@@ -713,6 +715,10 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
     const uint32_t total = *a.qcount;
     const GridGeom &g = a.g;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // One wave scanning every point answers a stray query (an outlier far from the cloud) in
+    // microseconds, where the tiled brute-force kernel would keep a single lane on it for the
+    // whole cloud; with very many such queries that kernel fills the GPU and takes over.
+    const int n_radii = (a.n_radii == 5 && total > a.all_gate) ? 4 : a.n_radii;
 
     for (uint32_t pos = blockIdx.x * WAVES + w; pos < total; pos += gridDim.x * WAVES) {
         const uint32_t entry = a.qlist[pos];
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         // larger and larger cubes until the K-th distance is certified (the wave is uniform
         // in the query, so the escalation costs no divergence)
 #pragma unroll 1
-        for (int ri = first_radius; ri < a.n_radii && !certified; ++ri) {
+        for (int ri = first_radius; ri < n_radii && !certified; ++ri) {
             const int R = a.wave_radii[ri];
             x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
             y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
@@ -1765,13 +1771,18 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.wave_radii[2] = 4;
     a.wave_radii[3] = 8;
     a.n_radii = 4;
-    // 1-NN searches end with the whole grid as the last "cube": for the handful of queries that
-    // are left (points far from the cloud) one wave scanning every point costs less than a launch
-    // of the tiled brute-force kernel, which is then not needed at all
-    const bool wave_does_all = nn_only && ix->nvalid <= (size_t)4 << 20;
-    if (wave_does_all) {
+    // Clouds of up to 4 M points end with the whole grid as the last "cube": for the queries that
+    // are left (points far from the cloud) one wave scanning every point costs far less than the
+    // tiled brute-force kernel, where a single lane would work through the whole cloud.  1-NN
+    // searches then need no brute-force launch at all; longer lists keep it for tie overflows and
+    // for floods of stray queries (all_gate).
+    const bool wave_all = ix->nvalid <= (size_t)4 << 20;
+    const bool wave_does_all = nn_only && wave_all;  // one neighbour: no list can overflow
+    a.all_gate = 0xFFFFFFFFu;
+    if (wave_all) {
         a.wave_radii[4] = 1 << 20;
         a.n_radii = 5;
+        if (!nn_only) a.all_gate = 65536u;
     }
     a.qmode = 2;
     a.qlist = listA;

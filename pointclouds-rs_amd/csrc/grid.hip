@@ -658,6 +658,21 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
     const int ny = y1 - y0 + 1;
     const int nrows = ny * (z1 - z0 + 1);
     const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1) {
+        // the whole grid is the whole sorted array: a linear scan, eight steps in flight
+        for (uint32_t t0 = 0; t0 < a.nvalid; t0 += 8 * 64) {
+            float4 p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t t = t0 + j * 64 + lane;
+                p[j] = t < a.nvalid ? a.spts[t] : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (t0 + j * 64 < a.nvalid) f(p[j], t0 + j * 64 + lane < a.nvalid, t0 + j * 64 + lane);
+        }
+        return;
+    }
     for (int rbase = 0; rbase < nrows; rbase += 64) {
         const int r = rbase + lane;
         uint32_t ms0 = 0, ms1 = 0;

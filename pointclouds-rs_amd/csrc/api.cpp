@@ -949,6 +949,8 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
     return PCRS_OK;
 }
 
+constexpr size_t kHostStatsBelow = 200000;
+
 int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n, uint32_t k,
              float std_mul, uint8_t *keep, size_t *n_keep, float *thr_out, float *mean_out) {
     if (!keep && n) return PCRS_ERR_INVALID_ARG;
@@ -976,28 +978,49 @@ int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size
     }
     pcrs_index *ix = nullptr;
     PCRS_TRY(pcrs_index_build(ctx, x, y, z, n, k + 1, PCRS_ALGO_AUTO, &ix));
-    DevBuf dmean;
-    int rc = dmean.alloc(ctx, n * sizeof(float)) == hipSuccess
+    DevBuf dmean, dkeep;
+    int rc = (dmean.alloc(ctx, n * sizeof(float)) == hipSuccess &&
+              dkeep.alloc(ctx, n) == hipSuccess)
                  ? PCRS_OK
                  : pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed");
     if (rc == PCRS_OK) rc = pcrs_sor_mean_dist_dev(ix, 0, n, k, dmean.as<float>());
-    if (rc == PCRS_OK) rc = download(ctx, mean_out, dmean.p, n * sizeof(float));
-    if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
-        rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed");
-    pcrs_index_destroy(ix);
-    if (rc != PCRS_OK) return rc;
-    float thr;
+    float thr = 0.0f;
+    int ok = 0;
     size_t kept = 0;
-    if (!host_threshold(mean_out, n, std_mul, &thr)) {
-        std::memset(keep, 0, n);
-    } else {
-        if (thr_out) *thr_out = thr;
+    if (rc == PCRS_OK) rc = download(ctx, mean_out, dmean.p, n * sizeof(float));
+    if (n < kHostStatsBelow) {
+        // The caller gets the means anyway, and below a few hundred thousand of them the two
+        // sequential passes cost the host less than the chain of small kernels costs the device.
+        if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed");
+        pcrs_index_destroy(ix);
+        if (rc != PCRS_OK) return rc;
+        if (!host_threshold(mean_out, n, std_mul, &thr)) {
+            std::memset(keep, 0, n);
+            return PCRS_OK;
+        }
         for (size_t i = 0; i < n; ++i) {
             keep[i] = mean_out[i] <= thr ? 1 : 0;
             kept += keep[i];
         }
+        if (thr_out) *thr_out = thr;
+        if (n_keep) *n_keep = kept;
+        return PCRS_OK;
     }
-    if (n_keep) *n_keep = kept;
+    // threshold and mask on the device (the sequential sums included); the means travel back
+    // while the statistics run
+    if (rc == PCRS_OK)
+        rc = pcrs_sor_select_dev(ctx, dmean.as<float>(), n, std_mul, dmean.as<float>(), n,
+                                 dkeep.as<uint8_t>(), &thr, &ok, &kept);
+    if (rc == PCRS_OK) rc = download(ctx, keep, dkeep.p, n);
+    if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed");
+    pcrs_index_destroy(ix);
+    if (rc != PCRS_OK) return rc;
+    if (ok) {
+        if (thr_out) *thr_out = thr;
+        if (n_keep) *n_keep = kept;
+    }
     return PCRS_OK;
 }
 

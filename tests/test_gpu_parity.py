@@ -508,6 +508,19 @@ def test_query_subrange_equals_full(oracle):
         eng.destroy_index(ix)
 
 
+def test_sor_host_call_large_cloud(hip, oracle):
+    """pcrs_sor with the means returned switches from host to device statistics at 200 K points:
+    both sides of the switch against the oracle (mask, count, threshold bit for bit)."""
+    for n in (150_000, 260_000):
+        x, y, z = gen.uniform_cloud(n, 21)
+        x[::9973] = np.nan  # a few non-finite points: their means are not part of the sums
+        keep, n_keep, thr, mean = hip.sor(x, y, z, 8, 1.5)
+        rkeep, rn, rthr, rmean = oracle.sor(x, y, z, 8, 1.5, algo=1)
+        assert np.array_equal(mean.view(np.uint32), rmean.view(np.uint32))
+        assert np.array_equal(keep, rkeep) and n_keep == rn
+        assert F(thr).view(np.uint32) == F(rthr).view(np.uint32)
+
+
 def test_slot_runs_equal_full(oracle):
     """Ownership by space: the runs of whole cells that pcrs_index_slot_bounds hands out
     partition the cloud, and the answers of a run are exactly the single-call answers of the

@@ -217,6 +217,11 @@ void pcrs_ctx_destroy(pcrs_ctx *ctx) {
     for (auto &pe : ctx->pool) (void)hipFree(pe.p);
     for (hipEvent_t e : ctx->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_stop) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->copy_event) (void)hipEventDestroy(ctx->copy_event);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -814,16 +819,15 @@ int pcrs_sor_mask_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float thr, ui
 
 // statistical_outlier.rs:43-66 without leaving the device between the statistics and the mask:
 // the threshold comes from ALL means (dmean_all), the mask covers the caller's own range (dmean).
-int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
-                        const float *dmean, size_t n, uint8_t *dkeep, float *thr, int *has_finite,
-                        size_t *n_keep) {
-    PCRS_TRY(bind_device(ctx));
-    if (thr) *thr = std::numeric_limits<float>::quiet_NaN();
-    if (has_finite) *has_finite = 0;
-    if (n_keep) *n_keep = 0;
-    if (n_all == 0) return PCRS_OK;
-    if (!dmean_all || (n && (!dmean || !dkeep)))
-        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+// Queues statistics, mask and the publication of {scalars, kept count} into pinned memory;
+// select_finish decodes them once the stream has been synchronised.
+struct SelectPending {
+    void *pin = nullptr;
+    size_t sb = 0;
+};
+
+static int select_launch(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
+                         const float *dmean, size_t n, uint8_t *dkeep, SelectPending *pend) {
     const size_t sb = (pcrs_sor_stats_scalars_bytes() + 63) & ~(size_t)63;
     const size_t wb = pcrs_sor_stats_workspace(n_all);
     void *scratch = nullptr;
@@ -835,16 +839,38 @@ int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, flo
     PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb));
     PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount));
     PCRS_TRY(pcrs_launch_publish(ctx, sc, pin, sb + 64));
-    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    pend->pin = pin;
+    pend->sb = sb;
+    return PCRS_OK;
+}
+
+static void select_finish(const SelectPending &pend, float *thr, int *has_finite, size_t *n_keep) {
     float t;
     int ok;
-    pcrs_sor_stats_decode(pin, nullptr, &t, &ok);
+    pcrs_sor_stats_decode(pend.pin, nullptr, &t, &ok);
     if (ok) {
         if (thr) *thr = t;
         if (has_finite) *has_finite = 1;
         if (n_keep)
-            *n_keep = (size_t)*reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(pin) + sb);
+            *n_keep = (size_t)*reinterpret_cast<unsigned long long *>(
+                reinterpret_cast<char *>(pend.pin) + pend.sb);
     }
+}
+
+int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
+                        const float *dmean, size_t n, uint8_t *dkeep, float *thr, int *has_finite,
+                        size_t *n_keep) {
+    PCRS_TRY(bind_device(ctx));
+    if (thr) *thr = std::numeric_limits<float>::quiet_NaN();
+    if (has_finite) *has_finite = 0;
+    if (n_keep) *n_keep = 0;
+    if (n_all == 0) return PCRS_OK;
+    if (!dmean_all || (n && (!dmean || !dkeep)))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    SelectPending pend;
+    PCRS_TRY(select_launch(ctx, dmean_all, n_all, std_mul, dmean, n, dkeep, &pend));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    select_finish(pend, thr, has_finite, n_keep);
     return PCRS_OK;
 }
 
@@ -905,6 +931,8 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
     DevBuf dmean, dnx, dny, dnz;
     int rc = PCRS_OK;
     auto fail = [&](int code) {
+        // nothing may still read the buffers that are released on the way out
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
         pcrs_index_destroy(ix);
         return code;
     };
@@ -920,27 +948,46 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
                               run_n ? dnz.as<float>() : nullptr);
     if (rc != PCRS_OK) return fail(rc);
     // statistics and mask stay on the device (statistical_outlier.rs:43-66): only the mask, the
-    // normals and three scalars cross PCIe
+    // normals and three scalars cross PCIe.  The normals are final once the search is through, so
+    // they travel on a second stream while the statistics run.
     DevBuf dkeep;
     float thr = std::numeric_limits<float>::quiet_NaN();
     int has_finite = 0;
     size_t kept = 0;
+    SelectPending pend;
+    const bool overlap = run_n && run_sor;
+    if (overlap) {
+        if (!ctx->copy_stream &&
+            (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming) != hipSuccess))
+            return fail(pcrs_set_err(ctx, PCRS_ERR_HIP, "copy stream creation failed"));
+        if (hipEventRecord(ctx->copy_event, ctx->stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event, 0) != hipSuccess)
+            return fail(pcrs_set_err(ctx, PCRS_ERR_HIP, "event ordering failed"));
+    }
     if (run_sor) {
         if (dkeep.alloc(ctx, n) != hipSuccess)
             return fail(pcrs_set_err(ctx, PCRS_ERR_OOM, "device allocation failed"));
-        rc = pcrs_sor_select_dev(ctx, dmean.as<float>(), n, std_mul, dmean.as<float>(), n,
-                                 dkeep.as<uint8_t>(), &thr, &has_finite, &kept);
-        if (rc == PCRS_OK) rc = download(ctx, keep, dkeep.p, n);
+        rc = select_launch(ctx, dmean.as<float>(), n, std_mul, dmean.as<float>(), n,
+                           dkeep.as<uint8_t>(), &pend);
         if (rc != PCRS_OK) return fail(rc);
     }
     if (run_n) {
-        rc = download(ctx, nx, dnx.p, n * sizeof(float));
-        if (rc == PCRS_OK) rc = download(ctx, ny, dny.p, n * sizeof(float));
-        if (rc == PCRS_OK) rc = download(ctx, nz, dnz.p, n * sizeof(float));
+        hipStream_t cs = overlap ? ctx->copy_stream : ctx->stream;
+        const size_t nb = n * sizeof(float);
+        if (hipMemcpyAsync(nx, dnx.p, nb, hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            hipMemcpyAsync(ny, dny.p, nb, hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            hipMemcpyAsync(nz, dnz.p, nb, hipMemcpyDeviceToHost, cs) != hipSuccess)
+            return fail(pcrs_set_err(ctx, PCRS_ERR_HIP, "download of the normals failed"));
+    }
+    if (run_sor) {
+        rc = download(ctx, keep, dkeep.p, n);
         if (rc != PCRS_OK) return fail(rc);
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        (overlap && hipStreamSynchronize(ctx->copy_stream) != hipSuccess))
         return fail(pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed"));
+    if (run_sor) select_finish(pend, &thr, &has_finite, &kept);
     pcrs_index_destroy(ix);
     if (run_sor) {
         if (has_finite && thr_out) *thr_out = thr;

@@ -29,6 +29,10 @@ struct pcrs_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     int num_cus = 256;
+    // second stream for result copies that may overlap later kernels of the same call
+    // (created on first use); copy_event orders it behind the producing kernels
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_event = nullptr;
     // optional HIP-event bracketing of the neighbour-search kernel (benchmark instrumentation)
     bool timing = false;
     std::vector<hipEvent_t> ev_start, ev_stop;  // one pair per bracketed launch

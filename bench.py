@@ -73,12 +73,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # Rehearsal of the multi-rank code path on a box with ONE GPU (PCRS_BENCH_REHEARSE=1): every
+    # rank uses cuda:0 and the collectives run over gloo through host memory.  The line it prints
+    # exercises the control flow only and is marked as a rehearsal, never a measurement.
+    rehearse = world > 1 and os.environ.get("PCRS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback of the product path")
     torch.cuda.set_device(local_rank)
@@ -87,7 +96,7 @@ def main():
     from pointclouds_rs.dist import Collectives, HipEngine, shard_range, sor_normals_sharded
 
     engine = HipEngine(local_rank)
-    coll = Collectives(dist)
+    coll = Collectives(dist, stage_through_host=rehearse)
     n_total = args.points * world
     begin, end = shard_range(n_total, world, rank)
     # one cloud of n_total points at unit density: side 100 * world^(1/3); each rank generates
@@ -133,7 +142,8 @@ def main():
     kernel_ms, launches = engine.timing_read()
     engine.timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=engine.device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if rehearse else engine.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,7 +175,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
                 "workload": f"SOR k={K_SOR} std_mul={STD_MUL} + normals k={K_NRM}, uniform-random cloud, "
                             f"{args.points} points per GPU ({n_total} total), queries sharded over ranks",

@@ -195,15 +195,19 @@ class HipEngine:
 class Collectives:
     """torch.distributed wrappers; identity when the job has a single rank."""
 
-    def __init__(self, dist=None):
+    def __init__(self, dist=None, stage_through_host=False):
         self.dist = dist if (dist is not None and dist.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
+        # a backend without device collectives (gloo): device tensors go through host memory
+        self.stage = stage_through_host
 
     def all_gather_var(self, torch, local, counts):
         """Concatenation over ranks of 1-D tensors whose lengths are `counts` (known everywhere)."""
         if self.world == 1:
             return local
+        if self.stage and local.device.type != "cpu":
+            return self.all_gather_var(torch, local.cpu(), counts).to(local.device)
         maxc = max(counts)
         local = local.contiguous()
         if min(counts) == maxc:  # equal shards: one collective straight into the result
@@ -220,14 +224,19 @@ class Collectives:
     def all_reduce_sum(self, t):
         """In-place sum of a tensor over ranks."""
         if self.world > 1:
-            self.dist.all_reduce(t)
+            if self.stage and t.device.type != "cpu":
+                h = t.cpu()
+                self.dist.all_reduce(h)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t)
 
     def all_reduce_sum_f64(self, torch, arr, device):
         """Sums a small float64 NumPy vector over ranks (rank-order independent result)."""
         if self.world == 1:
             return arr
         # gather then add in rank order, so every rank obtains bit-identical sums
-        t = torch.from_numpy(arr.copy()).to(device)
+        t = torch.from_numpy(arr.copy()).to("cpu" if self.stage else device)
         outs = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t)
         acc = np.zeros_like(arr)

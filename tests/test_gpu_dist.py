@@ -39,23 +39,11 @@ def _worker(rank, world, port, q):
 
     from pointclouds_rs.dist import Collectives, HipEngine, shard_range, sor_normals_sharded
 
-    class HostStaged(Collectives):
-        """gloo has no device collectives here: gather on the host, return to the device."""
-
-        def all_gather_var(self, torch, local, counts):
-            out = Collectives.all_gather_var(self, torch, local.cpu(), counts)
-            return out.to(local.device)
-
-        def all_reduce_sum(self, t):
-            h = t.cpu()
-            self.dist.all_reduce(h)
-            t.copy_(h)
-
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = HipEngine(0)
-    coll = HostStaged(dist)
+    coll = Collectives(dist, stage_through_host=True)  # gloo has no device collectives here
     x, y, z = _cloud()
     n_total = len(x)
     b, e = shard_range(n_total, world, rank)

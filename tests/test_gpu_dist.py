@@ -30,6 +30,17 @@ def _cloud():
     return synth.kitti_scene(3, 51001, 2000, 1000)  # 58001 points: uneven shards
 
 
+def _target_normals(eng, tgt):
+    """Normals of the ICP target from the library itself (k = 12), as NumPy columns."""
+    cols = [eng.from_numpy(c) for c in tgt]
+    n = len(tgt[0])
+    out = [eng.empty(n) for _ in range(3)]
+    ix = eng.build_index(*cols, 12)
+    eng.sor_normals_range(ix, 0, n, 0, 12, (0.0, 0.0, 0.0), None, *out)
+    eng.destroy_index(ix)
+    return [t.cpu().numpy() for t in out]
+
+
 def _worker(rank, world, port, q):
     for p in (os.path.join(ROOT, "pointclouds-rs_amd"), HERE):
         if p not in sys.path:
@@ -56,6 +67,20 @@ def _worker(rank, world, port, q):
                         point=None if r["point"] is None else r["point"].cpu().numpy().view(np.uint32).copy(),
                         keep=r["keep"].cpu().numpy().copy(), mean=r["mean"].cpu().numpy().copy(),
                         normals=[r[c].cpu().numpy().copy() for c in ("nx", "ny", "nz")])
+    # sharded ICP (point-to-plane): source split over the ranks, target and normals replicated
+    from pointclouds_rs import _ffi, synth
+    from pointclouds_rs.dist import icp_sharded
+
+    tgt = synth.hemisphere(4000, 99, 5.0)
+    tn = _target_normals(eng, tgt)
+    P = np.stack(tgt, 1)
+    S = (P @ synth.rot_z(0.04).T + np.array([0.2, -0.1, 0.05], dtype=F)).astype(F)
+    sb, se = shard_range(len(S), world, rank)
+    r = icp_sharded(eng, coll, _ffi.ICP_POINT_TO_PLANE,
+                    [eng.from_numpy(np.ascontiguousarray(S[sb:se, a])) for a in range(3)], len(S),
+                    [eng.from_numpy(c) for c in tgt], [eng.from_numpy(c) for c in tn], 12, 0.0)
+    out["icp"] = dict(rot=list(r["rotation"]), t=list(r["translation"]), rmse=r["rmse"],
+                      fitness=r["fitness"], iters=r["num_iterations"])
     q.put(out)
     dist.destroy_process_group()
 
@@ -105,3 +130,17 @@ def test_two_ranks_both_ownerships(oracle):
             for got, ref in zip(r["normals"], rn):
                 assert np.abs(got.astype(np.float64) - ref[pt]).max() <= 1e-5
         assert np.array_equal(np.sort(np.concatenate(pts)), np.arange(n_total))
+    # ICP: both ranks hold the same transform, equal to the oracle's single-process run
+    from pointclouds_rs import synth
+
+    tgt = synth.hemisphere(4000, 99, 5.0)
+    tn = oracle.normals(*tgt, 12, algo=1)
+    src = oracle.apply_transform(*tgt, synth.rot_z(0.04), (0.2, -0.1, 0.05))
+    rc, ref, _ = oracle.icp(1, src, tgt, tn, max_iter=12, tol=0.0, algo=1)
+    assert outs[0]["icp"]["rot"] == outs[1]["icp"]["rot"] and outs[0]["icp"]["t"] == outs[1]["icp"]["t"]
+    for o in outs:
+        assert o["icp"]["iters"] == ref.num_iterations == 12
+        assert o["icp"]["fitness"] == ref.fitness
+        assert abs(o["icp"]["rmse"] - ref.rmse) <= 1e-4 * ref.rmse + 1e-6
+        assert np.allclose(o["icp"]["rot"], list(ref.rot), atol=2e-5)
+        assert np.allclose(o["icp"]["t"], list(ref.t), atol=5e-5)

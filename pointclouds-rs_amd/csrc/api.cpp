@@ -874,30 +874,6 @@ int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, flo
     return PCRS_OK;
 }
 
-// statistical_outlier.rs:43-62 on host memory: strictly left-to-right f32 sums.
-static bool host_threshold(const float *mean, size_t n, float std_mul, float *thr) {
-    size_t nf = 0;
-    float s = 0.0f;
-    for (size_t i = 0; i < n; ++i)
-        if (std::isfinite(mean[i])) {
-            s += mean[i];
-            ++nf;
-        }
-    if (nf == 0) return false;
-    const float nn = (float)nf;
-    const float mu = s / nn;
-    float v = 0.0f;
-    for (size_t i = 0; i < n; ++i)
-        if (std::isfinite(mean[i])) {
-            const float d = mean[i] - mu;
-            v += d * d;
-        }
-    v = v / nn;
-    const float sd = std::sqrt(v);
-    *thr = mu + std_mul * sd;
-    return true;
-}
-
 int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                      uint32_t k_sor, float std_mul, uint32_t k_normals, const float viewpoint[3],
                      uint8_t *keep, size_t *n_keep, float *thr_out, float *nx, float *ny,
@@ -996,8 +972,6 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
     return PCRS_OK;
 }
 
-constexpr size_t kHostStatsBelow = 200000;
-
 int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n, uint32_t k,
              float std_mul, uint8_t *keep, size_t *n_keep, float *thr_out, float *mean_out) {
     if (!keep && n) return PCRS_ERR_INVALID_ARG;
@@ -1035,25 +1009,6 @@ int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size
     int ok = 0;
     size_t kept = 0;
     if (rc == PCRS_OK) rc = download(ctx, mean_out, dmean.p, n * sizeof(float));
-    if (n < kHostStatsBelow) {
-        // The caller gets the means anyway, and below a few hundred thousand of them the two
-        // sequential passes cost the host less than the chain of small kernels costs the device.
-        if (rc == PCRS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
-            rc = pcrs_set_err(ctx, PCRS_ERR_HIP, "stream synchronize failed");
-        pcrs_index_destroy(ix);
-        if (rc != PCRS_OK) return rc;
-        if (!host_threshold(mean_out, n, std_mul, &thr)) {
-            std::memset(keep, 0, n);
-            return PCRS_OK;
-        }
-        for (size_t i = 0; i < n; ++i) {
-            keep[i] = mean_out[i] <= thr ? 1 : 0;
-            kept += keep[i];
-        }
-        if (thr_out) *thr_out = thr;
-        if (n_keep) *n_keep = kept;
-        return PCRS_OK;
-    }
     // threshold and mask on the device (the sequential sums included); the means travel back
     // while the statistics run
     if (rc == PCRS_OK)

@@ -509,8 +509,8 @@ def test_query_subrange_equals_full(oracle):
 
 
 def test_sor_host_call_large_cloud(hip, oracle):
-    """pcrs_sor with the means returned switches from host to device statistics at 200 K points:
-    both sides of the switch against the oracle (mask, count, threshold bit for bit)."""
+    """pcrs_sor with the means returned (device statistics and mask, means downloaded beside
+    them) on mid-size clouds with non-finite points: mask, count, threshold bit for bit."""
     for n in (150_000, 260_000):
         x, y, z = gen.uniform_cloud(n, 21)
         x[::9973] = np.nan  # a few non-finite points: their means are not part of the sums

@@ -87,3 +87,43 @@ def test_random_clouds(hip, oracle, kind, seed):
     cl = hip.euclidean_cluster(x, y, z, r, 2, 500)
     rcl = oracle.euclidean_cluster(x, y, z, r, 2, 500)
     assert len(cl) == len(rcl) and all(np.array_equal(a, b) for a, b in zip(cl, rcl))
+
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("kind", KINDS)
+def test_random_clouds_runs_of_cells(kind, seed):
+    """Ownership by runs of cells on the same awkward shapes (finite points only: a cloud with
+    non-finite points has no cell order to split): the runs partition the cloud and every answer
+    equals the answer of the index-range entry point for the point it names, bit for bit."""
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine(0)
+    torch = eng.torch
+    rng = np.random.default_rng(7000 + 100 * KINDS.index(kind) + seed)
+    n = int(rng.choice([64, 100, 1000, 5000, 9000]))
+    k = int(rng.choice([1, 5, 10, 16, 24, 33]))
+    parts = int(rng.choice([1, 2, 3, 5, 8]))
+    cols_h = [np.nan_to_num(c, nan=0.25, posinf=1.5, neginf=-1.5) for c in make_cloud(rng, kind, n)]
+    cols = [eng.from_numpy(c) for c in cols_h]
+    vp = (1.0, -2.0, 30.0)
+    ix = eng.build_index(*cols, k + 1, 2)
+    ref = [eng.empty(n) for _ in range(4)]
+    eng.sor_normals_range(ix, 0, n, k, k, vp, *ref)
+    bounds = eng.slot_bounds(ix, parts)
+    if bounds[-1] == 0:  # no grid for this cloud (coincident points): nothing to split
+        eng.destroy_index(ix)
+        return
+    assert bounds[0] == 0 and bounds[-1] == n and bounds == sorted(bounds)
+    seen = np.zeros(n, dtype=np.int64)
+    for r in range(parts):
+        b, c = bounds[r], bounds[r + 1] - bounds[r]
+        point = eng.empty(c, "int32")
+        out = [eng.empty(c) for _ in range(4)]
+        eng.sor_normals_slots(ix, b, c, k, k, vp, point, *out)
+        torch.cuda.synchronize()
+        pt = point.cpu().numpy().view(np.uint32)
+        seen[pt] += 1
+        for got, want in zip(out, ref):
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), want.cpu().numpy()[pt].view(np.uint32))
+    assert (seen == 1).all()
+    eng.destroy_index(ix)

@@ -227,9 +227,23 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_hist_kernel(const float *x,
     __syncthreads();
     const uint32_t begin = blockIdx.x * sp.per_blk;
     const uint32_t end = min(m, begin + sp.per_blk);
-    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
-        const float px = x[i], py = y[i], pz = z[i];
-        if (finite3(px, py, pz)) atomicAdd(&hist[cell_index(sp.g, px, py, pz) >> sp.shift], 1u);
+    // four points per thread in flight: a block is a few waves working through thousands of points
+    for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * GB_THREADS) {
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = i0 + j * GB_THREADS;
+            px[j] = py[j] = pz[j] = __builtin_nanf("");
+            if (i < end) {
+                px[j] = x[i];
+                py[j] = y[i];
+                pz[j] = z[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (finite3(px[j], py[j], pz[j]))
+                atomicAdd(&hist[cell_index(sp.g, px[j], py[j], pz[j]) >> sp.shift], 1u);
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < sp.nb; t += GB_THREADS)
@@ -247,11 +261,25 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_scatter_kernel(const float 
     __syncthreads();
     const uint32_t begin = blockIdx.x * sp.per_blk;
     const uint32_t end = min(m, begin + sp.per_blk);
-    for (uint32_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
-        const float px = x[i], py = y[i], pz = z[i];
-        if (finite3(px, py, pz)) {
-            const uint32_t at = atomicAdd(&cursor[cell_index(sp.g, px, py, pz) >> sp.shift], 1u);
-            tmp[at] = make_float4(px, py, pz, __uint_as_float(i));
+    for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * GB_THREADS) {
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = i0 + j * GB_THREADS;
+            px[j] = py[j] = pz[j] = __builtin_nanf("");
+            if (i < end) {
+                px[j] = x[i];
+                py[j] = y[i];
+                pz[j] = z[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (finite3(px[j], py[j], pz[j])) {
+                const uint32_t at =
+                    atomicAdd(&cursor[cell_index(sp.g, px[j], py[j], pz[j]) >> sp.shift], 1u);
+                tmp[at] = make_float4(px[j], py[j], pz[j], __uint_as_float(i0 + j * GB_THREADS));
+            }
         }
     }
 }

@@ -1105,6 +1105,7 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
     q.qz = cz;
     q.nq = n;
     q.coherent = coherent;
+    if (max_d >= 0.0f) q.useful_distance = max_d;  // NaN or negative: no bound
     KnnOut o;
     o.nn_idx = nn_idx;
     o.nn_d2 = nn_d2;

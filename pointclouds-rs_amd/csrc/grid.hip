@@ -418,6 +418,8 @@ struct CellArgs {
     int wave_radii[5];      // cube half-widths the wave-per-query kernel tries in turn; entry 0
                             // is only for queries flagged PCRS_HEAVY_FLAG in the list
     int n_radii;            // entries of wave_radii in use
+    float useful_d2;        // 1-NN only: neighbours beyond this squared distance are of no use
+                            // to the caller (+inf = no such bound)
     uint32_t all_gate;      // the fifth radius (the whole grid) only when at most this many
                             // queries entered the launch
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
@@ -852,7 +854,8 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
                 }
                 const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
                 const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
-                certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
+                certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f) ||
+                                           (K == 1 && a.useful_d2 < (m * m) * (1.0f - 2e-6f)));
             }
         }
         bool failed = !certified;
@@ -1148,7 +1151,10 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
             }
             const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
             const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
-            certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f));
+            // either the nearest point is certainly inside the cube, or everything outside it is
+            // farther than the caller cares about
+            certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
+                                       a.useful_d2 < (m * m) * (1.0f - 2e-6f));
         }
         if (!certified) {
             if (a.fail_list) {
@@ -1692,6 +1698,11 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.qy = q.qy;
     a.qz = q.qz;
     a.kcert = keff;
+    a.useful_d2 = __builtin_inff();
+    if (nn_only && q.useful_distance < __builtin_inff()) {
+        const float u = q.useful_distance * (1.0f + 1e-5f);  // sqrt and square round trip
+        a.useful_d2 = u * u;
+    }
     // neighbour identities are needed for everything except the SOR mean
     const bool collect = out.idx || out.dist || out.count || out.nx;
     uint32_t kc = 0;

@@ -173,6 +173,9 @@ struct KnnQuery {
     size_t out_offset = 0;  // self queries: first query is point out_offset of the cloud
     bool self = false;
     bool coherent = false;  // explicit queries already in a spatial order: do not sort them again
+    // 1-NN searches whose caller drops neighbours farther than this (correspondence.rs:30): a
+    // query whose searched cube already covers that distance is finished, found or not
+    float useful_distance = __builtin_inff();
 };
 
 // ---- brute force (knn_bf.hip)

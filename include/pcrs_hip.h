@@ -213,6 +213,26 @@ int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, flo
                         const float *dmean, size_t n, uint8_t *dkeep, float *thr, int *has_finite,
                         size_t *n_keep);
 
+/* pcrs_sor_select_dev for callers that cannot allocate (no counterpart in the reference):
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The same
+ * kernels work in a static device array of the library (PCRS_SOR_SELECT_STATIC_BYTES, held by
+ * every GPU the library runs on until the process ends) instead of the context's scratch, and the
+ * results stay on the device: *dresult (device memory, written on the context's stream) receives
+ * thr (NaN when no mean is finite), has_finite and n_keep.  The call allocates nothing, frees
+ * nothing and does not synchronise.  n_all is limited to PCRS_SOR_SELECT_STATIC_MAX means; beyond
+ * it the call fails with PCRS_ERR_INVALID_ARG.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two contexts, two threads) race. */
+#define PCRS_SOR_SELECT_STATIC_MAX ((size_t)1 << 22)
+#define PCRS_SOR_SELECT_STATIC_BYTES ((size_t)1536 * 1024)
+typedef struct pcrs_sor_select_result {
+    float thr;
+    int32_t has_finite;
+    uint64_t n_keep;
+} pcrs_sor_select_result;
+int pcrs_sor_select_static_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
+                               const float *dmean, size_t n, uint8_t *dkeep,
+                               pcrs_sor_select_result *dresult);
+
 /* statistical_outlier_removal(cloud, k, std_mul) — statistical_outlier.rs:4-69.
  * keep[n] is the inlier mask (the caller applies PointCloud::select,
  * crates/core/src/cloud.rs:103-140); *n_keep the survivor count; *thr_out

@@ -13,12 +13,11 @@
 // ------------------------------------------------------------------------------------ helpers
 
 int pcrs_set_err(pcrs_ctx *ctx, int code, const char *fmt, ...) {
-    char buf[512];
+    if (!ctx) return code;
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
     return code;
 }
 
@@ -193,6 +192,12 @@ int pcrs_ctx_create(int device, pcrs_ctx **out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
         cus > 0)
         ctx->num_cus = cus;
+    // the static scratch array of this device, resolved while set-up work is still allowed
+    if (pcrs_static_scratch(ctx, &ctx->static_scratch, &ctx->static_scratch_bytes) != PCRS_OK) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return PCRS_ERR_HIP;
+    }
     *out = ctx;
     return PCRS_OK;
 }
@@ -250,7 +255,7 @@ int pcrs_ctx_timing_read(pcrs_ctx *ctx, double *total_ms, uint64_t *launches) {
     return PCRS_OK;
 }
 
-const char *pcrs_last_error(const pcrs_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *pcrs_last_error(const pcrs_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
 int pcrs_ctx_synchronize(pcrs_ctx *ctx) {
     PCRS_TRY(bind_device(ctx));
@@ -872,6 +877,33 @@ int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, flo
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     select_finish(pend, thr, has_finite, n_keep);
     return PCRS_OK;
+}
+
+// The same three launches with the library's static device array as work space and the results
+// left on the device: no allocation, no release, no synchronisation (see pcrs_hip.h).
+int pcrs_sor_select_static_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
+                               const float *dmean, size_t n, uint8_t *dkeep,
+                               pcrs_sor_select_result *dresult) {
+    PCRS_TRY(bind_device(ctx));
+    if (!dresult || (n_all && !dmean_all) || (n && (!dmean || !dkeep)))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    const size_t sb = (pcrs_sor_stats_scalars_bytes() + 63) & ~(size_t)63;
+    const size_t wb = pcrs_sor_stats_workspace(n_all);
+    if (n_all > PCRS_SOR_SELECT_STATIC_MAX || sb + 64 + wb > ctx->static_scratch_bytes)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG,
+                            "pcrs_sor_select_static_dev handles at most %zu means (got %zu): use "
+                            "pcrs_sor_select_dev",
+                            (size_t)PCRS_SOR_SELECT_STATIC_MAX, n_all);
+    char *sc = reinterpret_cast<char *>(ctx->static_scratch);  // the resolved device address
+    unsigned long long *dcount = reinterpret_cast<unsigned long long *>(sc + sb);
+    // the array keeps the last call's contents: the scalars and the count are cleared by the two
+    // launchers, every other part of the work space is written before it is read
+    PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb));
+    if (n_all)  // with no means at all the mask is left alone, as in pcrs_sor_select_dev
+        PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount));
+    else
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(dcount, 0, sizeof(*dcount), ctx->stream));
+    return pcrs_launch_select_result(ctx, sc, dcount, dresult);
 }
 
 int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,

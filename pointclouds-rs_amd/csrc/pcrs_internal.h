@@ -21,7 +21,7 @@ struct pcrs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    std::string err;
+    char err[512] = {0};  // fixed storage: reporting an error never allocates or throws
     // pinned host staging for small scalar read-backs
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -29,6 +29,10 @@ struct pcrs_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     int num_cus = 256;
+    // this device's copy of the library's static scratch array (stats.hip), resolved once at
+    // context creation; the entry point that must not allocate works in it
+    void *static_scratch = nullptr;
+    size_t static_scratch_bytes = 0;
     // second stream for result copies that may overlap later kernels of the same call
     // (created on first use); copy_event orders it behind the producing kernels
     hipStream_t copy_stream = nullptr;
@@ -296,6 +300,12 @@ int pcrs_launch_mask_dev_thr(pcrs_ctx *ctx, const float *mean, size_t n, const v
 void pcrs_sor_stats_decode(const void *host_copy, float *mu, float *thr, int *has_finite);
 int pcrs_sor_threshold_impl(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
                             float *thr, int *has_finite);
+// Device address and size of the static scratch array on the current device (stats.hip); resolved
+// once per device.  Call with the device current.
+int pcrs_static_scratch(pcrs_ctx *ctx, void **ptr, size_t *bytes);
+// {thr, has_finite, n_keep} from the device scalars and the mask count into *d_result
+int pcrs_launch_select_result(pcrs_ctx *ctx, const void *d_scalars,
+                              const unsigned long long *d_count, pcrs_sor_select_result *d_result);
 
 // ---- host math (host_math.cpp)
 void pcrs_host_compose(const float ra[9], const float ta[3], const float rb[9], const float tb[3],

@@ -15,6 +15,8 @@
 //      applies (same binade going in, still inside it coming out) costs O(1); any other chunk
 //      (a binade crossing, the first elements, a wrong estimate) is summed element by element
 //      with real f32 adds.  The result is exact by construction; only speed depends on 1-3.
+#include <mutex>
+
 #include "knn_common.h"
 
 #pragma clang fp contract(off)
@@ -761,6 +763,53 @@ int pcrs_launch_mask_dev_thr(pcrs_ctx *ctx, const float *mean, size_t n, const v
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(mask_dev_thr_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mean,
                        n, reinterpret_cast<const StatsScalars *>(d_scalars), keep, d_count);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Work space for the entry point that must not allocate (pcrs_sor_select_static_dev): a static
+// device array instead of the context's grown-on-demand scratch.  Every GPU the library runs on
+// holds its own copy at its own address; the name below is only a host-side handle, so the
+// address is resolved once per device and host code uses that pointer from then on.
+static __device__ __align__(256) unsigned char scratch[PCRS_SOR_SELECT_STATIC_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices];  // per device, nullptr = not resolved yet
+std::mutex g_scratch_mutex;
+}  // namespace
+
+int pcrs_static_scratch(pcrs_ctx *ctx, void **ptr, size_t *bytes) {
+    if (ctx->device < 0 || ctx->device >= kMaxDevices)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "device %d has no static scratch slot",
+                            ctx->device);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[ctx->device]) {
+        void *p = nullptr;
+        PCRS_HIP_CHECK(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[ctx->device] = p;
+    }
+    *ptr = g_scratch_ptr[ctx->device];
+    *bytes = sizeof(scratch);
+    return PCRS_OK;
+}
+
+namespace pcrs {
+__global__ void select_result_kernel(const StatsScalars *sc, const unsigned long long *count,
+                                     pcrs_sor_select_result *out) {
+    if (threadIdx.x != 0) return;
+    const bool any = sc->has_finite != 0;
+    out->thr = any ? sc->thr : __builtin_nanf("");
+    out->has_finite = any ? 1 : 0;
+    out->n_keep = any ? *count : 0ull;
+}
+}  // namespace pcrs
+
+int pcrs_launch_select_result(pcrs_ctx *ctx, const void *d_scalars,
+                              const unsigned long long *d_count, pcrs_sor_select_result *d_result) {
+    hipLaunchKernelGGL(pcrs::select_result_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       reinterpret_cast<const StatsScalars *>(d_scalars), d_count, d_result);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

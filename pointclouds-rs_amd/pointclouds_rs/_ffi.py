@@ -75,6 +75,7 @@ SIGNATURES = {
                                                           C.c_size_t, _V, _V, c_size_p, c_size_p]),
     "pcrs_sor_select_dev": (C.c_int, [_V, _V, C.c_size_t, C.c_float, _V, C.c_size_t, _V,
                                       C.POINTER(C.c_float), C.POINTER(C.c_int), c_size_p]),
+    "pcrs_sor_select_static_dev": (C.c_int, [_V, _V, C.c_size_t, C.c_float, _V, C.c_size_t, _V, _V]),
     "pcrs_radius_outlier_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, _V, _V,
                                                        c_size_p]),
     "pcrs_sor_mean_dist_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, _V]),

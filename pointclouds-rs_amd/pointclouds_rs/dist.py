@@ -128,6 +128,14 @@ class HipEngine:
                                                     C.byref(thr), C.byref(ok), C.byref(nk)))
         return float(thr.value), bool(ok.value), int(nk.value)
 
+    def select_static(self, mean_full, std_mul, mean, keep, result):
+        """pcrs_sor_select_static_dev: the same selection without any allocation or
+        synchronisation; `result` is a device tensor of 16 bytes that receives
+        {f32 thr, i32 has_finite, u64 n_keep}."""
+        self.ctx.check(self.lib.pcrs_sor_select_static_dev(
+            self.ctx.handle, self._p(mean_full), mean_full.numel(), float(std_mul), self._p(mean),
+            mean.numel(), self._p(keep), self._p(result)))
+
     def mask(self, mean, thr, keep, want_count=True):
         nk = C.c_size_t(0)
         self.ctx.check(self.lib.pcrs_sor_mask_dev(self.ctx.handle, self._p(mean), mean.numel(),

@@ -1233,6 +1233,47 @@ static void rigid_from_svd(const float *cx, const float *cy, const float *cz, co
     }
 }
 
+/* The point-to-point increment from f64 sums: NOT the reference's arithmetic (icp.rs:221-244
+ * accumulates centroids and H in f32) but the more accurate variant the GPU library computes
+ * (sums of s, t and s t^T in f64, H = sum s t^T - n sbar tbar^T), restated here sequentially so
+ * that the library's loop can be followed bit for bit.  The rotation comes out of the same
+ * Kabsch step, the translation is formed in f32 as icp.rs:264 does. */
+static void rigid_from_svd_f64(const float *cx, const float *cy, const float *cz, const float *tx,
+                               const float *ty, const float *tz, const uint32_t *tgt_idx, size_t n,
+                               size_t ncorr, orc_rigid *out) {
+    rigid_identity(out);
+    if (ncorr == 0) return;
+    double ss[3] = {0, 0, 0}, st[3] = {0, 0, 0}, sst[3][3] = {{0}};
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t ti = tgt_idx[i];
+        if (ti == 0xFFFFFFFFu) continue;
+        double s[3] = {cx[i], cy[i], cz[i]}, t[3] = {tx[ti], ty[ti], tz[ti]};
+        for (int a = 0; a < 3; ++a) {
+            ss[a] += s[a];
+            st[a] += t[a];
+            for (int b = 0; b < 3; ++b) sst[a][b] += s[a] * t[b];
+        }
+    }
+    double nn = (double)ncorr, sbar[3], tbar[3], H[3][3], R[3][3];
+    for (int a = 0; a < 3; ++a) {
+        sbar[a] = ss[a] / nn;
+        tbar[a] = st[a] / nn;
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) H[r][c] = sst[r][c] - nn * sbar[r] * tbar[c];
+    kabsch_rotation(H, R);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out->rot[r * 3 + c] = (float)R[r][c];
+    float sc[3] = {(float)sbar[0], (float)sbar[1], (float)sbar[2]};
+    float tc[3] = {(float)tbar[0], (float)tbar[1], (float)tbar[2]};
+    for (int r = 0; r < 3; ++r) {
+        float s = out->rot[r * 3 + 0] * sc[0];
+        s += out->rot[r * 3 + 1] * sc[1];
+        s += out->rot[r * 3 + 2] * sc[2];
+        out->t[r] = tc[r] - s;
+    }
+}
+
 /* 6x6 Cholesky solve; returns 0 when the matrix is not positive definite */
 static int chol6_solve(double A[6][6], const double b[6], double x[6]) {
     double L[6][6] = {{0}};
@@ -1404,7 +1445,8 @@ size_t orc_icp_step(const float *cx, const float *cy, const float *cz, size_t n,
     return nc;
 }
 
-/* icp.rs:125-206 (mode 0) and icp_plane.rs:20-97 (mode 1).
+/* icp.rs:125-206 (mode 0) and icp_plane.rs:20-97 (mode 1); mode 2 is mode 0 with the increment
+ * taken from f64 sums (rigid_from_svd_f64: the GPU library's arithmetic, not the reference's).
  * Returns 0 on success, -4 when mode 1 is given normals of the wrong length
  * (icp_plane.rs:27-32; signalled by tnx == NULL or m_normals != m).
  * trace (nullable): per iteration [rmse, fitness] pairs, capacity max_iter. */
@@ -1459,6 +1501,8 @@ int orc_icp(int mode, const float *sx, const float *sy, const float *sz, size_t 
         orc_rigid inc;
         if (mode == 0) {
             rigid_from_svd(cx, cy, cz, tx, ty, tz, tgt_idx, n, nc, &inc);
+        } else if (mode == 2) {
+            rigid_from_svd_f64(cx, cy, cz, tx, ty, tz, tgt_idx, n, nc, &inc);
         } else {
             double ata[36], atb[6];
             plane_normal_equations(cx, cy, cz, tx, ty, tz, tnx, tny, tnz, tgt_idx, n, ata, atb);

@@ -1120,6 +1120,11 @@ struct pcrs_icp {
     // target cells); perm[i] = original index of sorted point i, empty = original order kept
     DevBuf ord_s[3], perm;
     DevBuf state;  // IcpLoopState of pcrs_icp_run
+    // dist*dist of the correspondences of the last two iterations at their original source index
+    // (two halves of n floats, iteration i in half i & 1), and the work space of the
+    // left-to-right f32 sum over one of them (icp.rs:277-281)
+    DevBuf d2seq, seq_work;
+    size_t seq_scalars_bytes = 0;
 };
 
 namespace {
@@ -1129,22 +1134,21 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
                           const float *cy, const float *cz, size_t n, const float *tnx,
                           const float *tny, const float *tnz, float max_d, uint32_t *nn_idx,
                           float *nn_d2, double *dsums, uint32_t *tgt_out, float *dist_out,
-                          IcpLoopState *d_state = nullptr, size_t n_source = 0,
-                          float tolerance = 0.0f, bool coherent = false) {
+                          const IcpTail &tail = IcpTail(), bool coherent = false) {
     KnnQuery q;
     q.qx = cx;
     q.qy = cy;
     q.qz = cz;
     q.nq = n;
     q.coherent = coherent;
+    if (tail.state) q.skip_flag = &tail.state->done;
     if (max_d >= 0.0f) q.useful_distance = max_d;  // NaN or negative: no bound
     KnnOut o;
     o.nn_idx = nn_idx;
     o.nn_d2 = nn_d2;
     PCRS_TRY(run_query(target, q, o, 1));
     return pcrs_launch_icp_reduce(ctx, mode, cx, cy, cz, n, target->x, target->y, target->z, tnx,
-                                  tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums, d_state,
-                                  n_source, tolerance);
+                                  tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums, tail);
 }
 
 // Reorders the source spatially.  The sums of an ICP step do not depend on the order of the
@@ -1186,6 +1190,9 @@ int icp_alloc_work(pcrs_icp *icp) {
     PCRS_HIP_CHECK(ctx, icp->nn_d2.alloc(ctx, n * sizeof(float)));
     PCRS_HIP_CHECK(ctx, icp->sums.alloc(ctx, PCRS_ICP_NSUMS * sizeof(double)));
     PCRS_HIP_CHECK(ctx, icp->state.alloc(ctx, sizeof(IcpLoopState)));
+    PCRS_HIP_CHECK(ctx, icp->d2seq.alloc(ctx, 2 * n * sizeof(float)));
+    icp->seq_scalars_bytes = (pcrs_sor_stats_scalars_bytes() + 63) & ~(size_t)63;
+    PCRS_HIP_CHECK(ctx, icp->seq_work.alloc(ctx, icp->seq_scalars_bytes + pcrs_sor_stats_workspace(n)));
     return PCRS_OK;
 }
 
@@ -1356,7 +1363,7 @@ int pcrs_icp_accumulate(pcrs_icp *icp, int mode, float max_distance, double *sum
                                    icp->cur[1].as<float>(), icp->cur[2].as<float>(), icp->n,
                                    icp->tnx, icp->tny, icp->tnz, max_distance,
                                    icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
-                                   icp->sums.as<double>(), nullptr, nullptr, nullptr, 0, 0.0f,
+                                   icp->sums.as<double>(), nullptr, nullptr, IcpTail(),
                                    icp->perm.p != nullptr));
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, PCRS_ICP_NSUMS * sizeof(double), &pin));
@@ -1429,19 +1436,8 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
         return PCRS_OK;
     }
     PCRS_TRY(pcrs_icp_reset(icp));
-    if (max_iterations == 0) {  // icp.rs:190-197: one metrics pass, identity transform
-        double sums[PCRS_ICP_NSUMS];
-        PCRS_TRY(pcrs_icp_accumulate(icp, mode, max_correspondence_distance, sums));
-        out->rmse = std::numeric_limits<float>::infinity();
-        if (sums[0] > 0.0) {
-            out->rmse = (float)std::sqrt(sums[1] / sums[0]);       // icp.rs:273-282
-            out->fitness = (float)(size_t)sums[0] / (float)icp->n;  // icp.rs:170
-        }
-        return PCRS_OK;
-    }
-    // The loop state lives on the device (icp_tail_kernel carries icp.rs:147-188), so the host
-    // only looks at it every few iterations; iterations queued behind the end of the loop are
-    // no-ops.
+    // The loop state lives on the device (icp_tail_step carries icp.rs:147-188), so the host only
+    // looks at it every few iterations; iterations queued behind the end of the loop are no-ops.
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState), &pin));
     IcpLoopState *hs = reinterpret_cast<IcpLoopState *>(pin);
@@ -1453,22 +1449,56 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     PCRS_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, sizeof(*hs), hipMemcpyHostToDevice, ctx->stream));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // hs is reused for the read-backs
     float *cx = icp->cur[0].as<float>(), *cy = icp->cur[1].as<float>(), *cz = icp->cur[2].as<float>();
+    // The convergence test |prev_rmse - rmse| < tolerance (icp.rs:173) can only fire for a
+    // positive tolerance.  Then every iteration takes its rmse from the reference's own sum
+    // (dist*dist in source order, left to right in f32), so that the loop ends in the iteration
+    // in which the reference ends.  Otherwise the f64 tree sum steers nothing, and only the rmse
+    // that is reported is recomputed that way after the loop.
+    IcpTail tail;
+    tail.state = ds;
+    tail.n_source = icp->n;
+    tail.tolerance = tolerance;
+    tail.exact = tolerance > 0.0f;
+    tail.perm = icp->perm.as<uint32_t>();  // null when the source kept its order
+    tail.seq_scalars = icp->seq_work.p;
+    tail.seq_work = reinterpret_cast<char *>(icp->seq_work.p) + icp->seq_scalars_bytes;
+    tail.seq_work_bytes = icp->seq_work.bytes - icp->seq_scalars_bytes;
+    auto iteration = [&](uint32_t it) {
+        tail.d2seq = icp->d2seq.as<float>() + (size_t)(it & 1u) * icp->n;
+        return correspond_and_reduce(ctx, icp->target, mode, cx, cy, cz, icp->n, icp->tnx, icp->tny,
+                                     icp->tnz, max_correspondence_distance,
+                                     icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
+                                     icp->sums.as<double>(), nullptr, nullptr, tail,
+                                     icp->perm.p != nullptr);
+    };
+    if (max_iterations == 0) {  // icp.rs:190-197: one metrics pass, identity transform
+        tail.metrics_only = true;
+        tail.exact = true;
+        PCRS_TRY(iteration(0));
+    }
     constexpr uint32_t kBatch = 4;
     for (uint32_t iter = 0; iter < max_iterations;) {
         const uint32_t nb = std::min(kBatch, max_iterations - iter);
         for (uint32_t j = 0; j < nb; ++j) {
-            PCRS_TRY(correspond_and_reduce(ctx, icp->target, mode, cx, cy, cz, icp->n, icp->tnx,
-                                           icp->tny, icp->tnz, max_correspondence_distance,
-                                           icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
-                                           icp->sums.as<double>(), nullptr, nullptr, ds, icp->n,
-                                           tolerance, icp->perm.p != nullptr));  // the last kernel of
-                                                                                  // the reduction runs the tail
+            PCRS_TRY(iteration(iter + j));  // search, reduction and the tail of the iteration
             PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));  // icp.rs:186
         }
         iter += nb;
         PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));  // hs is pinned
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done) break;
+    }
+    if (max_iterations == 0) {
+        PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (!tail.exact && hs->last_live) {
+        // the reported rmse from the reference's sum over the last live iteration's distances
+        const float *d2 = icp->d2seq.as<float>() + (size_t)((hs->last_live - 1u) & 1u) * icp->n;
+        PCRS_TRY(pcrs_launch_seq_sum(ctx, d2, icp->n, tail.seq_scalars, tail.seq_work,
+                                     tail.seq_work_bytes));
+        PCRS_TRY(pcrs_launch_icp_exact_rmse(ctx, ds, tail.seq_scalars));
+        PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     std::memcpy(out->rotation, hs->cum_r, sizeof(hs->cum_r));
     std::memcpy(out->translation, hs->cum_t, sizeof(hs->cum_t));

@@ -427,6 +427,7 @@ struct CellArgs {
     uint32_t *fail_count;
     uint32_t kcert;         // neighbours that must be certified (<= K)
     uint32_t kcollect;      // neighbours whose identity is needed (pass 2), 0 = none
+    const uint32_t *skip;   // nullable device word: non-zero makes the launch a no-op
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Queries come in
@@ -490,6 +491,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
     __shared__ uint32_t lst[COLLECT ? CAP : 1][GB_THREADS];  // slots of the hits, walk order
     __shared__ uint8_t ord[COLLECT ? CAP : 1][GB_THREADS];   // ord[r] = list position of rank r
 
+    if (a.skip && *a.skip) return;
     uint32_t total = a.nq;
     if (a.qmode >= 2) total = *a.qcount;
     const GridGeom &g = a.g;
@@ -757,6 +759,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
     __shared__ uint32_t wl_slot[WAVES][64];
     __shared__ uint64_t wl_key[WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (a.skip && *a.skip) return;
     const uint32_t total = *a.qcount;
     const GridGeom &g = a.g;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -862,6 +865,8 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
 
         uint32_t have = 0;
         if (!failed && COLLECT && K == 1) {
+            // beyond the caller's bound: not a usable neighbour (and possibly not the nearest)
+            if (D[0] > a.useful_d2) best1 = PCRS_EMPTY_KEY;
             if (lane == 0) wl_key[w][0] = best1;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             have = best1 != PCRS_EMPTY_KEY ? 1u : 0u;
@@ -999,6 +1004,7 @@ __global__ __launch_bounds__(GB_THREADS) void owned_write_kernel(const float4 *s
 constexpr int NN_SUB = 8;
 
 __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut out) {
+    if (a.skip && *a.skip) return;
     uint32_t total = a.nq;
     if (a.qmode == 2 || a.qmode == 4) total = *a.qcount;
     const GridGeom &g = a.g;
@@ -1163,8 +1169,12 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
             }
             continue;
         }
-        out.nn_idx[qi] = (best == PCRS_EMPTY_KEY) ? PCRS_NO_INDEX : key_idx(best);
-        if (out.nn_d2) out.nn_d2[qi] = best_d2;
+        // A query certified only because everything outside the cube is beyond the caller's
+        // bound may hold a point of the cube that is neither within the bound nor the nearest
+        // one: it has no neighbour the caller can use, and is stored as such.
+        const bool none = best == PCRS_EMPTY_KEY || best_d2 > a.useful_d2;
+        out.nn_idx[qi] = none ? PCRS_NO_INDEX : key_idx(best);
+        if (out.nn_d2) out.nn_d2[qi] = none ? __builtin_inff() : best_d2;
     }
 }
 
@@ -1698,6 +1708,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.qy = q.qy;
     a.qz = q.qz;
     a.kcert = keff;
+    a.skip = q.skip_flag;
     a.useful_d2 = __builtin_inff();
     if (nn_only && q.useful_distance < __builtin_inff()) {
         const float u = q.useful_distance * (1.0f + 1e-5f);  // sqrt and square round trip

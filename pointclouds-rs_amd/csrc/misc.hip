@@ -126,8 +126,10 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
     const float *cx, const float *cy, const float *cz, uint32_t n, const float *tx,
     const float *ty, const float *tz, const float *tnx, const float *tny, const float *tnz,
     const uint32_t *nn_idx, const float *nn_d2, float max_d, uint32_t *tgt_idx_out,
-    float *dist_out, double *partials) {
+    float *dist_out, double *partials, float *d2seq, const uint32_t *perm,
+    const IcpLoopState *st) {
     constexpr int NS = (MODE == PCRS_ICP_POINT_TO_PLANE) ? 29 : 17;
+    if (st && st->done) return;  // queued behind the end of the loop
     double acc[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) acc[i] = 0.0;
@@ -143,9 +145,11 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
         }
         if (tgt_idx_out) tgt_idx_out[i] = valid ? ti : PCRS_NO_INDEX;
         if (dist_out) dist_out[i] = valid ? dist : __builtin_nanf("");
+        const float dd = dist * dist;  // icp.rs:279, product rounded to f32
+        if (d2seq) d2seq[perm ? perm[i] : i] = valid ? dd : 0.0f;
         if (!valid) continue;
         acc[0] += 1.0;
-        acc[1] += (double)(dist * dist);  // icp.rs:279, product rounded to f32
+        acc[1] += (double)dd;
         const double sx = cx[i], sy = cy[i], sz = cz[i];
         const double px = tx[ti], py = ty[ti], pz = tz[ti];
         if (MODE == PCRS_ICP_POINT_TO_PLANE) {
@@ -192,18 +196,28 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
 }
 
 // What the host does between two iterations of the ICP loop (icp.rs:147-188), for one thread.
+// exact_sum (nullable): the left-to-right f32 sum of dist*dist in source order (icp.rs:277-281);
+// without it the rmse comes from the f64 tree sum, within ~1e-5 relative of the former.
 __device__ inline void icp_tail_step(int mode, const double *sums, float n_source, float tolerance,
-                                IcpLoopState *st) {
+                                     bool metrics_only, const float *exact_sum, IcpLoopState *st) {
     if (st->done) return;
-    st->num_iterations += 1u;
+    if (!metrics_only) st->num_iterations += 1u;
     if (!(sums[0] > 0.0)) {  // icp.rs:163-165
         st->done = 1u;
         return;
     }
-    const float rmse = (float)sqrt(sums[1] / sums[0]);          // icp.rs:273-282
-    const float fitness = (float)(size_t)sums[0] / n_source;    // icp.rs:170
+    const float ncorr = (float)(size_t)sums[0];
+    const float rmse = exact_sum ? sqrtf(*exact_sum / ncorr)            // icp.rs:281
+                                 : (float)sqrt(sums[1] / sums[0]);
+    const float fitness = ncorr / n_source;  // icp.rs:170
     st->last_rmse = rmse;
     st->last_fitness = fitness;
+    st->last_ncorr = ncorr;
+    st->last_live = metrics_only ? 1u : st->num_iterations;
+    if (metrics_only) {  // icp.rs:190-197
+        st->done = 1u;
+        return;
+    }
     if (fabsf(st->prev_rmse - rmse) < tolerance) {  // icp.rs:173-176
         st->converged = 1u;
         st->done = 1u;
@@ -228,10 +242,12 @@ __device__ inline void icp_tail_step(int mode, const double *sums, float n_sourc
 
 // Stage 2: 32 groups of threads fold the block partials (group g takes blocks g, g+32, ... in
 // order), then 32 threads fold the groups in order: a fixed summation tree, a few microseconds.
-// With a loop state, thread 0 then runs the tail of the iteration on the fresh sums.
+// With tail_here, thread 0 then runs the tail of the iteration on the fresh sums.
 __global__ __launch_bounds__(1024) void icp_final_kernel(const double *partials, uint32_t nblocks,
                                                          double *sums, int mode, float n_source,
-                                                         float tolerance, IcpLoopState *st) {
+                                                         float tolerance, int metrics_only,
+                                                         int tail_here, IcpLoopState *st) {
+    if (st && st->done) return;
     __shared__ double grp[32][PCRS_ICP_NSUMS + 1];
     const int i = threadIdx.x & 31, gidx = threadIdx.x >> 5;
     double v = 0.0;
@@ -243,10 +259,11 @@ __global__ __launch_bounds__(1024) void icp_final_kernel(const double *partials,
         for (int q = 0; q < 32; ++q) t += grp[q][threadIdx.x];
         sums[threadIdx.x] = t;
     }
-    if (st) {
+    if (st && tail_here) {
         __threadfence_block();
         __syncthreads();
-        if (threadIdx.x == 0) icp_tail_step(mode, sums, n_source, tolerance, st);
+        if (threadIdx.x == 0)
+            icp_tail_step(mode, sums, n_source, tolerance, metrics_only != 0, nullptr, st);
     }
 }
 
@@ -370,8 +387,14 @@ int pcrs_launch_count_mask(pcrs_ctx *ctx, const uint32_t *count, size_t n, size_
 namespace pcrs {
 
 __global__ void icp_tail_kernel(int mode, const double *sums, float n_source, float tolerance,
-                                IcpLoopState *st) {
-    icp_tail_step(mode, sums, n_source, tolerance, st);
+                                int metrics_only, const float *exact_sum, IcpLoopState *st) {
+    icp_tail_step(mode, sums, n_source, tolerance, metrics_only != 0, exact_sum, st);
+}
+
+// After a loop whose rmse values came from the f64 sums (tolerance <= 0: the convergence test
+// can never fire, so only the reported value matters): the reported rmse from the exact sum.
+__global__ void icp_exact_rmse_kernel(IcpLoopState *st, const float *exact_sum) {
+    if (st->last_live) st->last_rmse = sqrtf(*exact_sum / st->last_ncorr);
 }
 
 __global__ __launch_bounds__(256) void transform_state_kernel(float *x, float *y, float *z, size_t n,
@@ -393,10 +416,22 @@ __global__ __launch_bounds__(256) void transform_state_kernel(float *x, float *y
 
 }  // namespace pcrs
 
-int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, size_t n_source,
-                         float tolerance, IcpLoopState *d_state) {
+int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, const IcpTail &tail) {
+    const float *exact_sum =
+        tail.exact ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(tail.seq_scalars) +
+                                                     pcrs_seq_sum_result_offset())
+                   : nullptr;
     hipLaunchKernelGGL(pcrs::icp_tail_kernel, dim3(1), dim3(1), 0, ctx->stream, mode, d_sums,
-                       (float)n_source, tolerance, d_state);
+                       (float)tail.n_source, tail.tolerance, tail.metrics_only ? 1 : 0, exact_sum,
+                       tail.state);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_icp_exact_rmse(pcrs_ctx *ctx, IcpLoopState *d_state, const void *d_seq_scalars) {
+    hipLaunchKernelGGL(pcrs::icp_exact_rmse_kernel, dim3(1), dim3(1), 0, ctx->stream, d_state,
+                       reinterpret_cast<const float *>(reinterpret_cast<const char *>(d_seq_scalars) +
+                                                       pcrs_seq_sum_result_offset()));
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
@@ -415,11 +450,18 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            const float *tz, const float *tnx, const float *tny, const float *tnz,
                            const uint32_t *nn_idx, const float *nn_d2, float max_d,
                            uint32_t *tgt_idx_out, float *dist_out, double *d_sums,
-                           IcpLoopState *d_state, size_t n_source, float tolerance) {
+                           const IcpTail &tail) {
+    IcpLoopState *st = tail.state;
+    if (tail.exact && (!tail.d2seq || !tail.seq_scalars || !tail.seq_work))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "exact rmse needs its work buffers");
     if (n == 0) {
         PCRS_HIP_CHECK(ctx,
                        hipMemsetAsync(d_sums, 0, PCRS_ICP_NSUMS * sizeof(double), ctx->stream));
-        if (d_state) return pcrs_launch_icp_tail(ctx, mode, d_sums, n_source, tolerance, d_state);
+        if (st) {
+            IcpTail t2 = tail;
+            t2.exact = false;  // no correspondences: the tail never looks at a sum
+            return pcrs_launch_icp_tail(ctx, mode, d_sums, t2);
+        }
         return PCRS_OK;
     }
     size_t blocks = (n + ICP_THREADS - 1) / ICP_THREADS;
@@ -431,13 +473,22 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
     if (mode == PCRS_ICP_POINT_TO_PLANE)
         hipLaunchKernelGGL(icp_partial_kernel<PCRS_ICP_POINT_TO_PLANE>, dim3((unsigned)blocks),
                            dim3(ICP_THREADS), 0, ctx->stream, cx, cy, cz, (uint32_t)n, tx, ty, tz,
-                           tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials);
+                           tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials,
+                           tail.d2seq, tail.perm, st);
     else
         hipLaunchKernelGGL(icp_partial_kernel<PCRS_ICP_POINT_TO_POINT>, dim3((unsigned)blocks),
                            dim3(ICP_THREADS), 0, ctx->stream, cx, cy, cz, (uint32_t)n, tx, ty, tz,
-                           tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials);
+                           tnx, tny, tnz, nn_idx, nn_d2, max_d, tgt_idx_out, dist_out, partials,
+                           tail.d2seq, tail.perm, st);
     hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, partials,
-                       (uint32_t)blocks, d_sums, mode, (float)n_source, tolerance, d_state);
+                       (uint32_t)blocks, d_sums, mode, (float)tail.n_source, tail.tolerance,
+                       tail.metrics_only ? 1 : 0, (st && !tail.exact) ? 1 : 0, st);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
+    if (st && tail.exact) {
+        // the reference's rmse: dist*dist summed left to right in f32, in source order
+        PCRS_TRY(pcrs_launch_seq_sum(ctx, tail.d2seq, n, tail.seq_scalars, tail.seq_work,
+                                     tail.seq_work_bytes));
+        PCRS_TRY(pcrs_launch_icp_tail(ctx, mode, d_sums, tail));
+    }
     return PCRS_OK;
 }

@@ -178,8 +178,13 @@ struct KnnQuery {
     bool self = false;
     bool coherent = false;  // explicit queries already in a spatial order: do not sort them again
     // 1-NN searches whose caller drops neighbours farther than this (correspondence.rs:30): a
-    // query whose searched cube already covers that distance is finished, found or not
+    // query whose searched cube already covers that distance is finished, found or not.  The
+    // grid kernels then store "no neighbour" (PCRS_NO_INDEX, +inf) for a query whose nearest
+    // point lies beyond the bound; the brute-force kernel stores the true nearest point.
     float useful_distance = __builtin_inff();
+    // device word that, when non-zero, turns the whole search into a no-op (an ICP iteration
+    // queued behind the end of its loop)
+    const uint32_t *skip_flag = nullptr;
 };
 
 // ---- brute force (knn_bf.hip)
@@ -275,11 +280,30 @@ struct IcpLoopState {
     uint32_t converged;
     uint32_t done;  // loop has ended (converged or no correspondences): later iterations are no-ops
     uint32_t num_iterations;
+    float last_ncorr;    // correspondence count behind last_rmse, as f32 (icp.rs:281)
+    uint32_t last_live;  // 1-based iteration that produced last_rmse (0 = none yet)
+};
+// What one iteration of the device-resident loop needs beyond the reduction itself.
+struct IcpTail {
+    IcpLoopState *state = nullptr;  // null: sums only, no loop
+    size_t n_source = 0;
+    float tolerance = 0.0f;
+    bool metrics_only = false;  // max_iterations == 0: one pass for rmse and fitness (icp.rs:190-197)
+    // d2seq (nullable): receives dist*dist of every correspondence (0 where there is none) at the
+    // point's ORIGINAL source index (perm undoes the spatial order of the working copy)
+    float *d2seq = nullptr;
+    const uint32_t *perm = nullptr;
+    // exact: the rmse of this iteration is the reference's left-to-right f32 sum over d2seq
+    // (icp.rs:277-281) instead of the f64 tree sum; needs seq_scalars / seq_work
+    bool exact = false;
+    void *seq_scalars = nullptr, *seq_work = nullptr;
+    size_t seq_work_bytes = 0;
 };
 // After the sums of an iteration are in d_sums: metrics, convergence test, solve, compose
 // (pcrs_launch_icp_reduce does the same inside its last kernel when given a loop state).
-int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, size_t n_source,
-                         float tolerance, IcpLoopState *d_state);
+int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, const IcpTail &tail);
+// last_rmse of the state from the exact sum left by pcrs_launch_seq_sum in d_seq_scalars
+int pcrs_launch_icp_exact_rmse(pcrs_ctx *ctx, IcpLoopState *d_state, const void *d_seq_scalars);
 // cur = inc(cur) with the increment read from the device state; no-op once the loop is done.
 int pcrs_launch_transform_state(pcrs_ctx *ctx, float *x, float *y, float *z, size_t n,
                                 const IcpLoopState *d_state);
@@ -288,10 +312,14 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            const float *tz, const float *tnx, const float *tny, const float *tnz,
                            const uint32_t *nn_idx, const float *nn_d2, float max_d,
                            uint32_t *tgt_idx_out, float *dist_out, double *d_sums,
-                           IcpLoopState *d_state = nullptr, size_t n_source = 0,
-                           float tolerance = 0.0f);
+                           const IcpTail &tail);
 // SOR global statistics with the reference's left-to-right f32 summation, on the device (stats.hip)
 size_t pcrs_sor_stats_workspace(size_t n);
+// Left-to-right f32 sum of n non-negative values with the same machinery; the sum is the float at
+// byte pcrs_seq_sum_result_offset() of d_scalars.  Work space as for the statistics.
+int pcrs_launch_seq_sum(pcrs_ctx *ctx, const float *values, size_t n, void *d_scalars, void *d_work,
+                        size_t work_bytes);
+size_t pcrs_seq_sum_result_offset();
 size_t pcrs_sor_stats_scalars_bytes();
 int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
                           void *d_scalars, void *d_work, size_t work_bytes);

@@ -230,7 +230,10 @@ PCRS_HD inline void solve_plane(const double *sums, float rot[9], float t[3]) {
         return;
     }
     const float ax = alpha / angle, ay = beta / angle, az = gamma / angle;
-    const float c = cos(angle), sn = sin(angle), tt = 1.0f - c;
+    // evaluated in f64 and rounded once: the device's own f32 cos / sin are a unit in the last
+    // place off a correctly rounded libm now and then, and one such bit moves the whole
+    // trajectory of the loop away from the host's
+    const float c = (float)cos((double)angle), sn = (float)sin((double)angle), tt = 1.0f - c;
     rot[0] = tt * ax * ax + c;
     rot[1] = tt * ax * ay - sn * az;
     rot[2] = tt * ax * az + sn * ay;

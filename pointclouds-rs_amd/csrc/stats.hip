@@ -15,6 +15,7 @@
 //      applies (same binade going in, still inside it coming out) costs O(1); any other chunk
 //      (a binade crossing, the first elements, a wrong estimate) is summed element by element
 //      with real f32 adds.  The result is exact by construction; only speed depends on 1-3.
+#include <cstddef>
 #include <mutex>
 
 #include "knn_common.h"
@@ -44,13 +45,18 @@ struct Composite {
     uint32_t pad;
 };
 
-// element i of pass P: pass 1 = finite mean (else 0), pass 2 = (mean - mu)^2 of finite means
+// element i of pass P: pass 1 = finite mean (else 0), pass 2 = (mean - mu)^2 of finite means,
+// pass 3 = the value itself (a plain left-to-right sum of non-negative numbers; +inf stays +inf)
 template <int PASS>
 __device__ __forceinline__ float stat_element(const float *mean, size_t n, size_t i, float mu,
                                               bool *finite) {
     *finite = false;
     if (i >= n) return 0.0f;
     const float d = mean[i];
+    if (PASS == 3) {
+        *finite = true;
+        return d;
+    }
     if (!(d - d == 0.0f)) return 0.0f;  // inf / NaN are filtered out (:43-47)
     *finite = true;
     if (PASS == 1) return d;
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
         const float nn = (float)sc->nf;  // finite_dists.len() as f32
         if (PASS == 1) {
             sc->mu = s / nn;
-        } else {
+        } else if (PASS == 2) {
             const float var = s / nn;
             const float sd = sqrtf(var);
             sc->sigma = sd;
@@ -687,51 +693,86 @@ static void run_pass(pcrs_ctx *ctx, int W, const float *dmean, size_t n, StatsSc
     }
 }
 
+// The work space of one statistics run, carved out of one allocation.
+struct StatsWork {
+    uint32_t nchunks, nspans;
+    int W;
+    double *csum;
+    Composite *comp, *bcomp;
+    uint32_t *ccnt;
+    float *cmax;
+    double *ssum;
+    unsigned long long *scnt;
+    float *smax;
+};
+
+static StatsWork carve_work(size_t n, void *d_work) {
+    StatsWork k;
+    k.nchunks = (uint32_t)((n + ST_CHUNK - 1) / ST_CHUNK);
+    k.W = stats_window(n);
+    char *w = reinterpret_cast<char *>(d_work);
+    k.csum = reinterpret_cast<double *>(w);
+    k.comp = reinterpret_cast<Composite *>(w + (size_t)k.nchunks * sizeof(double));
+    char *after = w + (size_t)k.nchunks * (sizeof(double) + (size_t)k.W * sizeof(Composite));
+    k.ccnt = reinterpret_cast<uint32_t *>(after);
+    k.cmax = reinterpret_cast<float *>(after + (size_t)k.nchunks * sizeof(uint32_t));
+    k.nspans = (k.nchunks + ST_SCAN_SPAN - 1) / ST_SCAN_SPAN;
+    uintptr_t sp = reinterpret_cast<uintptr_t>(k.cmax + k.nchunks);
+    sp = (sp + 7u) & ~(uintptr_t)7u;
+    k.ssum = reinterpret_cast<double *>(sp);
+    k.scnt = reinterpret_cast<unsigned long long *>(k.ssum + k.nspans);
+    k.smax = reinterpret_cast<float *>(k.scnt + k.nspans);
+    uintptr_t bp = reinterpret_cast<uintptr_t>(k.smax + k.nspans);
+    bp = (bp + 15u) & ~(uintptr_t)15u;
+    k.bcomp = reinterpret_cast<Composite *>(bp);
+    return k;
+}
+
+// chunk sums -> f64 prefix -> composites -> walk, for one pass
+template <int PASS>
+static void run_whole_pass(pcrs_ctx *ctx, const StatsWork &k, const float *v, size_t n,
+                           StatsScalars *sc, int write_count, float std_mul) {
+    hipLaunchKernelGGL(chunk_sums_kernel<PASS>, dim3((k.nchunks + 3) / 4), dim3(256), 0, ctx->stream,
+                       v, n, sc, k.csum, k.ccnt, k.cmax, k.nchunks);
+    hipLaunchKernelGGL(chunk_scan_local_kernel, dim3(k.nspans), dim3(1024), 0, ctx->stream, k.csum,
+                       k.ccnt, k.cmax, k.nchunks, k.ssum, k.scnt, k.smax, sc, write_count);
+    if (k.nspans > 1)
+        hipLaunchKernelGGL(chunk_scan_base_kernel, dim3(k.nspans), dim3(1024), 0, ctx->stream,
+                           k.csum, k.nchunks, k.ssum, k.scnt, k.smax, sc, write_count);
+    run_pass<PASS>(ctx, k.W, v, n, sc, k.csum, k.comp, k.bcomp, k.nchunks, std_mul);
+}
+
 // Runs both passes; leaves {mu, thr, sigma, has_finite, nf} in *d_scalars (device).  No host sync.
 int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
                           void *d_scalars, void *d_work, size_t work_bytes) {
-    const uint32_t nchunks = (uint32_t)((n + ST_CHUNK - 1) / ST_CHUNK);
-    const size_t need = pcrs_sor_stats_workspace(n);
-    if (work_bytes < need)
+    if (work_bytes < pcrs_sor_stats_workspace(n))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "stats workspace too small");
     StatsScalars *sc = reinterpret_cast<StatsScalars *>(d_scalars);
-    char *w = reinterpret_cast<char *>(d_work);
-    const int W = stats_window(n);
-    double *csum = reinterpret_cast<double *>(w);
-    Composite *comp = reinterpret_cast<Composite *>(w + (size_t)nchunks * sizeof(double));
-    char *after = w + (size_t)nchunks * (sizeof(double) + (size_t)W * sizeof(Composite));
-    uint32_t *ccnt = reinterpret_cast<uint32_t *>(after);
-    float *cmax = reinterpret_cast<float *>(after + (size_t)nchunks * sizeof(uint32_t));
-    const uint32_t nspans = (nchunks + ST_SCAN_SPAN - 1) / ST_SCAN_SPAN;
-    uintptr_t sp = reinterpret_cast<uintptr_t>(cmax + nchunks);
-    sp = (sp + 7u) & ~(uintptr_t)7u;
-    double *ssum = reinterpret_cast<double *>(sp);
-    unsigned long long *scnt = reinterpret_cast<unsigned long long *>(ssum + nspans);
-    float *smax = reinterpret_cast<float *>(scnt + nspans);
-    uintptr_t bp = reinterpret_cast<uintptr_t>(smax + nspans);
-    bp = (bp + 15u) & ~(uintptr_t)15u;
-    Composite *bcomp = reinterpret_cast<Composite *>(bp);
-    auto scan = [&](int write_count) {
-        hipLaunchKernelGGL(chunk_scan_local_kernel, dim3(nspans), dim3(1024), 0, ctx->stream, csum,
-                           ccnt, cmax, nchunks, ssum, scnt, smax, sc, write_count);
-        if (nspans > 1)
-            hipLaunchKernelGGL(chunk_scan_base_kernel, dim3(nspans), dim3(1024), 0, ctx->stream,
-                               csum, nchunks, ssum, scnt, smax, sc, write_count);
-    };
     PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
     if (n == 0) return PCRS_OK;
-    const dim3 cgrid((nchunks + 3) / 4), cblock(256);
-    // pass 1: mean
-    hipLaunchKernelGGL(chunk_sums_kernel<1>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
-    scan(1);
-    run_pass<1>(ctx, W, dmean, n, sc, csum, comp, bcomp, nchunks, std_mul);
-    // pass 2: variance
-    hipLaunchKernelGGL(chunk_sums_kernel<2>, cgrid, cblock, 0, ctx->stream, dmean, n, sc, csum, ccnt, cmax, nchunks);
-    scan(0);
-    run_pass<2>(ctx, W, dmean, n, sc, csum, comp, bcomp, nchunks, std_mul);
+    const StatsWork k = carve_work(n, d_work);
+    run_whole_pass<1>(ctx, k, dmean, n, sc, 1, std_mul);  // mean
+    run_whole_pass<2>(ctx, k, dmean, n, sc, 0, std_mul);  // variance
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
+
+// The left-to-right f32 sum of n non-negative values (what `iter().sum::<f32>()` gives), left in
+// the `run` field of *d_scalars; pcrs_seq_sum_result_offset() tells where that float lies.
+int pcrs_launch_seq_sum(pcrs_ctx *ctx, const float *values, size_t n, void *d_scalars, void *d_work,
+                        size_t work_bytes) {
+    if (work_bytes < pcrs_sor_stats_workspace(n))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "stats workspace too small");
+    StatsScalars *sc = reinterpret_cast<StatsScalars *>(d_scalars);
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
+    if (n == 0) return PCRS_OK;
+    const StatsWork k = carve_work(n, d_work);
+    run_whole_pass<3>(ctx, k, values, n, sc, 1, 0.0f);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+size_t pcrs_seq_sum_result_offset() { return offsetof(StatsScalars, run); }
 
 // Binades per chunk composite.  After i adds the f32 sum is within a factor 1 -+ i 2^-24 of the
 // exact prefix; elements far below half an ulp (squared deviations) all round the same way, so

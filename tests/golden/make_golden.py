@@ -57,12 +57,18 @@ def main():
     out["icp/step/point"] = st["point"]
     out["icp/step/sum_d2"] = np.float64(st["sum_d2"])
     out["icp/step/tgt_idx"] = st["tgt_idx"]
-    for mode, tag in ((0, "p2p"), (1, "p2plane")):
-        rc, res, trace = o.icp(mode, src, tgt, tn, max_iter=50, tol=0.0, algo=0, with_trace=True)
-        out[f"icp/{tag}/rot"] = np.array(res.rot, dtype=np.float32)
-        out[f"icp/{tag}/t"] = np.array(res.t, dtype=np.float32)
-        out[f"icp/{tag}/rmse_fitness_iters"] = np.array([res.rmse, res.fitness, res.num_iterations], dtype=np.float64)
-        out[f"icp/{tag}/trace"] = trace
+    # mode 2 = point-to-point with the increment from f64 sums (what the GPU library computes;
+    # mode 0 is the reference's own f32 accumulation).  "_tol": with the default tolerance, so
+    # that the iteration in which the loop ends and the converged flag are part of the vector.
+    for mode, tag in ((0, "p2p"), (1, "p2plane"), (2, "p2p_f64")):
+        for tol, suffix in ((0.0, ""), (1e-5, "_tol")):
+            rc, res, trace = o.icp(mode, src, tgt, tn, max_iter=50, tol=tol, algo=0, with_trace=True)
+            key = f"icp/{tag}{suffix}"
+            out[f"{key}/rot"] = np.array(res.rot, dtype=np.float32)
+            out[f"{key}/t"] = np.array(res.t, dtype=np.float32)
+            out[f"{key}/rmse_fitness_iters"] = np.array([res.rmse, res.fitness, res.num_iterations], dtype=np.float64)
+            out[f"{key}/converged"] = np.int32(res.converged)
+            out[f"{key}/trace"] = trace
     path = os.path.join(HERE, "oracle_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -137,3 +137,33 @@ def test_clustered_3m_sampled_parity():
     assert np.array_equal(mean.cpu().numpy()[sample].view(np.uint32), ref.view(np.uint32))
     ln = nx * nx + ny * ny + nz * nz
     assert float((ln - 1.0).abs().max().item()) <= 1e-5
+
+
+@pytest.mark.timeout(300)
+def test_c3_icp_100k_properties(oracle):
+    """Point-to-plane ICP of two 100 K-point scans, 50 iterations (the registration the benchmark
+    times): every iteration runs, every source point keeps a correspondence, the motion is
+    recovered, and the reported rmse is the reference's own sum (icp.rs:273-282: dist*dist left
+    to right in f32, in source order) over the correspondences of the 50th iteration — checked
+    by stopping a second run after 49 iterations and handing its working copy to the oracle."""
+    from pointclouds_rs import hip, synth
+
+    n = 100_000
+    tgt = synth.hemisphere(n, 99, 5.0)
+    tn = hip.normals(*tgt, 16)
+    t0 = np.array([0.3, -0.2, 0.1], dtype=F)
+    src = hip.apply_transform(*tgt, synth.rot_z(0.05), t0)
+    icp = hip.Icp(src, tgt, tn)
+    r49 = icp.run(1, 49, 0.0)
+    assert r49.num_iterations == 49 and not r49.converged
+    cur = icp.current()
+    step = oracle.icp_step(cur, tgt, tn, np.inf, algo=1)
+    res = icp.run(1, 50, 0.0)
+    icp.close()
+    assert res.num_iterations == 50 and not res.converged
+    assert res.fitness == 1.0 and step["n_corr"] == n
+    assert F(res.rmse).view(np.uint32) == F(step["rmse"]).view(np.uint32), (res.rmse, step["rmse"])
+    assert res.rmse < 2e-5  # the f32 noise floor of coordinates of magnitude 5
+    R = np.array(res.rotation, dtype=np.float64).reshape(3, 3)
+    assert np.allclose(R, synth.rot_z(-0.05), atol=1e-5)
+    assert np.allclose(np.array(res.translation), -(R @ t0.astype(np.float64)), atol=1e-5)

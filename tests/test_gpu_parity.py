@@ -339,7 +339,8 @@ def test_correspondences_and_step_sums(hip, oracle, algo):
         p = icp.accumulate(_ffi.ICP_POINT_TO_POINT, max_d)
         assert p[0] == ref["n_corr"]
         assert np.allclose(p[2:17], ref["point"], rtol=1e-11, atol=1e-12)
-        # rmse from the f64 sum vs the reference's sequential f32 sum: within 1e-5 relative
+        # the f64 sum the accumulate call returns vs the reference's sequential f32 sum (which
+        # pcrs_icp_run reproduces exactly): within 1e-5 relative
         assert abs(np.sqrt(s[1] / s[0]) - ref["rmse"]) <= 1e-5 * ref["rmse"]
     icp.close()
 
@@ -408,6 +409,29 @@ def test_icp_current_keeps_caller_order(hip, oracle, n):
     icp.close()
 
 
+def _bits(v):
+    return np.asarray(v, dtype=F).view(np.uint32)
+
+
+def _assert_same_run(res, ref):
+    """The whole outcome of a registration: where the loop ended and why and the metrics bit
+    for bit, the accumulated transform to a few units in the last place of 1.0 (on the noise
+    floor an entry of 1e-9 of an increment may round the other way without moving any point)."""
+    assert int(res.num_iterations) == int(ref.num_iterations)
+    assert bool(res.converged) == bool(ref.converged)
+    assert _bits(res.fitness) == _bits(ref.fitness)
+    assert _bits(res.rmse) == _bits(ref.rmse), (res.rmse, ref.rmse)
+    assert np.allclose(np.array(res.rotation), np.array(ref.rot), rtol=0, atol=2.5e-7)
+    assert np.allclose(np.array(res.translation), np.array(ref.t), rtol=0, atol=2.5e-7)
+
+
+# Which oracle loop the library must follow bit for bit: point-to-plane sums in f64 in the
+# reference itself (icp_plane.rs:148-180); for point-to-point the library sums in f64 where the
+# reference sums in f32 (icp.rs:221-244), so its twin is the oracle's f64 variant (mode 2) and
+# the reference's own arithmetic (mode 0) is met within the noise of those f32 sums.
+ORACLE_TWIN = {0: 2, 1: 1}
+
+
 @pytest.mark.parametrize("mode", [0, 1], ids=["point", "plane"])
 def test_icp_run_matches_oracle(hip, oracle, mode):
     tgt = _icp_pair(4000)
@@ -415,33 +439,52 @@ def test_icp_run_matches_oracle(hip, oracle, mode):
     src = oracle.apply_transform(*tgt, gen.rot_z(0.05), (0.3, -0.2, 0.1))
     # tolerance 0 never fires (|d rmse| < 0 is false): all iterations run, as in the benchmark
     res = hip.icp_register(mode, src, tgt, tn, 30, 0.0, np.inf)
-    rc, ref, _ = oracle.icp(mode, src, tgt, tn, max_iter=30, tol=0.0, algo=1)
-    assert rc == 0 and res.num_iterations == ref.num_iterations == 30
-    assert not res.converged and not ref.converged
-    assert abs(res.fitness - ref.fitness) == 0
-    assert abs(res.rmse - ref.rmse) <= 1e-5 * max(ref.rmse, 1e-3)
-    assert np.allclose(np.array(res.rotation), np.array(ref.rot), atol=2e-5)
-    assert np.allclose(np.array(res.translation), np.array(ref.t), atol=5e-5)
+    rc, ref, _ = oracle.icp(ORACLE_TWIN[mode], src, tgt, tn, max_iter=30, tol=0.0, algo=1)
+    assert rc == 0 and ref.num_iterations == 30 and not ref.converged
+    _assert_same_run(res, ref)
+    if mode == 0:  # against the reference's f32 sums: equal up to their noise
+        rc, lit, _ = oracle.icp(0, src, tgt, tn, max_iter=30, tol=0.0, algo=1)
+        assert res.num_iterations == lit.num_iterations and res.fitness == lit.fitness
+        assert np.allclose(np.array(res.rotation), np.array(lit.rot), atol=2e-5)
+        assert np.allclose(np.array(res.translation), np.array(lit.t), atol=5e-5)
     # and the registration actually recovers the inverse motion
     assert np.allclose(np.array(res.rotation).reshape(3, 3), gen.rot_z(-0.05), atol=2e-2)
 
 
-def test_icp_with_tolerance_and_gate(hip, oracle):
-    tgt = _icp_pair(3000)
+@pytest.mark.parametrize("n,tol,max_d", [(3000, 1e-5, 1.0), (3000, 1e-3, np.inf), (12000, 1e-6, 0.5),
+                                         (700, 1e-4, np.inf)])
+def test_icp_loop_control_matches_oracle(hip, oracle, n, tol, max_d):
+    """With a live tolerance the loop must stop in the iteration in which the reference's stops:
+    the rmse of every iteration is the reference's left-to-right f32 sum in source order
+    (icp.rs:273-282), so num_iterations, converged and the rmse are identical, not merely close.
+    n = 12000 runs with the source reordered inside the library, n = 700 on the brute-force
+    index."""
+    tgt = _icp_pair(n)
     tn = oracle.normals(*tgt, 16, algo=1)
     src = oracle.apply_transform(*tgt, gen.rot_z(0.03), (0.1, 0.05, -0.05))
     for mode in (0, 1):
-        res = hip.icp_register(mode, src, tgt, tn, 50, 1e-5, 1.0)
-        rc, ref, _ = oracle.icp(mode, src, tgt, tn, max_iter=50, tol=1e-5, max_d=1.0, algo=1)
-        assert bool(res.converged) == bool(ref.converged)
-        assert abs(int(res.num_iterations) - int(ref.num_iterations)) <= 1
-        # rmse ends on the f32 noise floor of the coordinates (|p| ~ 5, ulp 4.8e-7)
-        assert abs(res.rmse - ref.rmse) <= 1e-4 * ref.rmse + 1e-6
+        res = hip.icp_register(mode, src, tgt, tn, 50, tol, max_d)
+        rc, ref, _ = oracle.icp(ORACLE_TWIN[mode], src, tgt, tn, max_iter=50, tol=tol, max_d=max_d,
+                                algo=1)
+        assert rc == 0 and 1 < ref.num_iterations < 50 and ref.converged
+        _assert_same_run(res, ref)
+
+
+def test_icp_metrics_pass_and_lost_correspondences(hip, oracle):
+    tgt = _icp_pair(3000)
+    src = oracle.apply_transform(*tgt, gen.rot_z(0.03), (0.1, 0.05, -0.05))
     # max_iterations == 0: one metrics pass (icp.rs:190-197)
     res = hip.icp_register(0, src, tgt, None, 0, 1e-5, np.inf)
     rc, ref, _ = oracle.icp(0, src, tgt, None, max_iter=0, tol=1e-5, algo=1)
-    assert res.num_iterations == 0 and res.fitness == ref.fitness
-    assert abs(res.rmse - ref.rmse) <= 1e-5 * ref.rmse
+    assert res.num_iterations == 0
+    _assert_same_run(res, ref)
+    # a gate nothing passes: the loop ends in its first iteration without metrics (icp.rs:163-165)
+    far = oracle.apply_transform(*tgt, gen.rot_z(0.0), (100.0, 0.0, 0.0))
+    for tol in (0.0, 1e-5):
+        res = hip.icp_register(0, far, tgt, None, 20, tol, 1.0)
+        rc, ref, _ = oracle.icp(2, far, tgt, None, max_iter=20, tol=tol, max_d=1.0, algo=1)
+        assert ref.num_iterations == 1 and not ref.converged and np.isinf(ref.rmse)
+        _assert_same_run(res, ref)
 
 
 def test_kitti_scene_sor(hip, oracle):
@@ -659,3 +702,24 @@ def test_search_stage_statistics():
     ix.close()
     assert st["grid_tile"] + st["grid_ring"] + st["brute"] == len(x)
     assert st["grid_tile"] > 0.9 * len(x) and st["grid_ring"] > 0
+
+
+def test_correspondences_bounded_on_a_target_beyond_the_whole_grid_scan(hip, oracle):
+    """Targets above 4 M points have no whole-grid scan by one wave as their last search stage:
+    what the cubes leave goes to the tiled brute-force kernel.  With a finite
+    max_correspondence_distance the searches also end at the cube that covers that distance."""
+    tx, ty, tz = gen.uniform_cloud(4_300_000, 21, 0, 100)
+    rng = np.random.default_rng(9)
+    q = np.concatenate([
+        rng.uniform(0, 100, size=(3000, 3)),      # inside the cloud
+        rng.uniform(-3, 103, size=(1500, 3)),     # around its faces
+        rng.uniform(-400, 500, size=(150, 3)),    # far outside
+        np.array([[np.nan, 1, 1], [50, 50, np.inf]]),
+    ]).astype(F)
+    ix = hip.Index(tx, ty, tz, k_hint=1, algo=2)
+    for max_d in (0.4, 2.5, np.inf):
+        t, d, n = ix.find_correspondences(q[:, 0], q[:, 1], q[:, 2], max_d)
+        rt, rd, rn = oracle.find_correspondences(q[:, 0], q[:, 1], q[:, 2], tx, ty, tz, max_d, algo=1)
+        assert n == rn and np.array_equal(t, rt)
+        assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+    ix.close()

@@ -204,10 +204,12 @@ int pcrs_ctx_create(int device, pcrs_ctx **out) {
 
 int pcrs_ctx_set_stream(pcrs_ctx *ctx, void *hip_stream) {
     PCRS_TRY(bind_device(ctx));
-    if (ctx->own_stream && ctx->stream) {
-        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        PCRS_HIP_CHECK(ctx, hipStreamDestroy(ctx->stream));
-    }
+    // Pooled buffers, the scratch and the pinned read-back area are reused in stream order: work
+    // still in flight on the old stream (or on the copy stream) must be through before the
+    // first call on the new one can touch them, whoever owns the old stream.
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->own_stream && ctx->stream) PCRS_HIP_CHECK(ctx, hipStreamDestroy(ctx->stream));
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
     return PCRS_OK;

@@ -48,7 +48,9 @@ class HipEngine:
 
         self.torch = torch
         self.device = torch.device("cuda", device_index)
-        self.ctx = _ffi.get_context(device_index)
+        # a context of its own: pointing the process-wide context of pointclouds_rs.hip at
+        # torch's stream would silently move every later hip.* call onto that stream too
+        self.ctx = _ffi.Context(device_index)
         if use_torch_stream:
             self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.lib = self.ctx.lib

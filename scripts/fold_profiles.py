@@ -19,7 +19,18 @@ with open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w", newline="") a
         w.writerow([name, calls, int(total_us * 1000), round(avg_us * 1000, 1), round(pct, 2)])
 dirs = sorted(glob.glob(os.path.join(src, "pmc_*")))
 dirs = [d for d in dirs if os.path.isdir(d)]
-out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "pmc_summary.py")] + dirs)
-with open(os.path.join(dst, tag + "_pmc_counters.json"), "wb") as f:
-    f.write(out)
+out = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "pmc_summary.py")] + dirs))
+# which state of the kernels the counters belong to, and the dominant kernel's duration in the
+# kernel trace of the same command (the bench prices the counters with it)
+commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+dirty = subprocess.call(["git", "-C", ROOT, "diff", "--quiet", "--", "pointclouds-rs_amd/csrc"]) != 0
+kernel_ms = None
+for name, calls, total_us, avg_us, pct in con.execute(
+        "select name,total_calls,total_duration,average,percentage from top_kernels"):
+    if "knn_cell_kernel<17, true>" in name:
+        kernel_ms = avg_us / 1000.0
+out["_meta"] = {"commit": commit + ("+uncommitted kernel changes" if dirty else ""), "kernel_ms": kernel_ms,
+                "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stages --icp-iters 0"}
+with open(os.path.join(dst, tag + "_pmc_counters.json"), "w") as f:
+    json.dump(out, f, indent=1)
 print("wrote", dst)

@@ -4,12 +4,12 @@
 # folded into profiles/ by scripts/fold_profiles.py.  Delete the local gpurun_out/prof_<tag>/ of an
 # earlier run first: results merge into it, and the fold would average old and new launches.
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-args="$R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stages"
+args="$R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stages --icp-iters 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/trace" -o kt -- python3 $args > "$out/trace.log" 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -- python3 $args > "$out/pmc_fetch.log" 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -- python3 $args > "$out/pmc_write.log" 2>&1 || exit 1

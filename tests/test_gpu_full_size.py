@@ -159,6 +159,13 @@ def test_c3_icp_100k_properties(oracle):
     cur = icp.current()
     step = oracle.icp_step(cur, tgt, tn, np.inf, algo=1)
     res = icp.run(1, 50, 0.0)
+    # with the reference's default tolerance the loop must end where the oracle's ends
+    # (same inputs, normals included), on the same rmse
+    live = icp.run(1, 50, 1e-5)
+    rc, ref, _ = oracle.icp(1, src, tgt, tn, max_iter=50, tol=1e-5, algo=1)
+    assert rc == 0 and 1 < ref.num_iterations < 50 and ref.converged
+    assert live.num_iterations == ref.num_iterations and bool(live.converged)
+    assert F(live.rmse).view(np.uint32) == F(ref.rmse).view(np.uint32), (live.rmse, ref.rmse)
     icp.close()
     assert res.num_iterations == 50 and not res.converged
     assert res.fitness == 1.0 and step["n_corr"] == n

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <exception>
 #include <new>
 
 #include "pcrs_internal.h"
@@ -19,6 +20,20 @@ int pcrs_set_err(pcrs_ctx *ctx, int code, const char *fmt, ...) {
     vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+// Called from the catch-all of every entry point: nothing may unwind through the C boundary
+// (the caller is Rust, C or ctypes).  Turns the exception in flight into a status code.
+int pcrs_on_exception(pcrs_ctx *ctx) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return pcrs_set_err(ctx, PCRS_ERR_HIP, "internal error: %s", e.what());
+    } catch (...) {
+        return pcrs_set_err(ctx, PCRS_ERR_HIP, "internal error: unknown exception");
+    }
 }
 
 int pcrs_ctx_scratch(pcrs_ctx *ctx, size_t bytes, void **out) {
@@ -81,6 +96,7 @@ hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap) {
         e = hipMalloc(p, want);
     }
     if (e == hipSuccess) *cap = want;
+    else (void)hipGetLastError();  // do not leave the failure for a later check to find
     return e;
 }
 
@@ -130,6 +146,8 @@ int bind_device(pcrs_ctx *ctx) {
 }
 
 int upload(pcrs_ctx *ctx, DevBuf &dst, const float *src, size_t n) {
+    if (n >= 0xFFFFFFFFull)  // also keeps n * sizeof(float) from wrapping around
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points (got %zu)", n);
     PCRS_HIP_CHECK(ctx, dst.alloc(ctx, n * sizeof(float)));
     if (n) PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dst.p, src, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     return PCRS_OK;
@@ -174,7 +192,7 @@ extern "C" {
 
 const char *pcrs_version(void) { return "pcrs-hip 0.1 (gfx950)"; }
 
-int pcrs_ctx_create(int device, pcrs_ctx **out) {
+int pcrs_ctx_create(int device, pcrs_ctx **out) try {
     if (!out) return PCRS_ERR_INVALID_ARG;
     *out = nullptr;
     int count = 0;
@@ -200,9 +218,11 @@ int pcrs_ctx_create(int device, pcrs_ctx **out) {
     }
     *out = ctx;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(nullptr);
 }
 
-int pcrs_ctx_set_stream(pcrs_ctx *ctx, void *hip_stream) {
+int pcrs_ctx_set_stream(pcrs_ctx *ctx, void *hip_stream) try {
     PCRS_TRY(bind_device(ctx));
     // Pooled buffers, the scratch and the pinned read-back area are reused in stream order: work
     // still in flight on the old stream (or on the copy stream) must be through before the
@@ -213,9 +233,11 @@ int pcrs_ctx_set_stream(pcrs_ctx *ctx, void *hip_stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
-void pcrs_ctx_destroy(pcrs_ctx *ctx) {
+void pcrs_ctx_destroy(pcrs_ctx *ctx) try {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -231,17 +253,20 @@ void pcrs_ctx_destroy(pcrs_ctx *ctx) {
     if (ctx->copy_event) (void)hipEventDestroy(ctx->copy_event);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+} catch (...) {
 }
 
-int pcrs_ctx_timing(pcrs_ctx *ctx, int enable) {
+int pcrs_ctx_timing(pcrs_ctx *ctx, int enable) try {
     PCRS_TRY(bind_device(ctx));
     ctx->timing = enable != 0;
     ctx->ev_used = 0;
     ctx->timing_depth = 0;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
-int pcrs_ctx_timing_read(pcrs_ctx *ctx, double *total_ms, uint64_t *launches) {
+int pcrs_ctx_timing_read(pcrs_ctx *ctx, double *total_ms, uint64_t *launches) try {
     PCRS_TRY(bind_device(ctx));
     if (!total_ms || !launches) return PCRS_ERR_INVALID_ARG;
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -255,20 +280,24 @@ int pcrs_ctx_timing_read(pcrs_ctx *ctx, double *total_ms, uint64_t *launches) {
     *launches = ctx->ev_used;
     ctx->ev_used = 0;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 const char *pcrs_last_error(const pcrs_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
-int pcrs_ctx_synchronize(pcrs_ctx *ctx) {
+int pcrs_ctx_synchronize(pcrs_ctx *ctx) try {
     PCRS_TRY(bind_device(ctx));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 // -------------------------------------------------------------------------------------- index
 
 int pcrs_index_build_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
-                         size_t m, uint32_t k_hint, int algo, pcrs_index **out) {
+                         size_t m, uint32_t k_hint, int algo, pcrs_index **out) try {
     if (!out) return PCRS_ERR_INVALID_ARG;
     *out = nullptr;
     PCRS_TRY(bind_device(ctx));
@@ -288,10 +317,12 @@ int pcrs_index_build_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const 
     }
     *out = ix;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_index_build(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t m,
-                     uint32_t k_hint, int algo, pcrs_index **out) {
+                     uint32_t k_hint, int algo, pcrs_index **out) try {
     if (!out) return PCRS_ERR_INVALID_ARG;
     *out = nullptr;
     PCRS_TRY(bind_device(ctx));
@@ -317,19 +348,22 @@ int pcrs_index_build(pcrs_ctx *ctx, const float *x, const float *y, const float 
     }
     *out = ix;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
-void pcrs_index_destroy(pcrs_index *index) {
+void pcrs_index_destroy(pcrs_index *index) try {
     if (!index) return;
     // Grid buffers return to the context's pool (stream-ordered reuse, no wait); buffers uploaded
     // from host memory are hipFree'd, which waits for the device by itself.
     if (index->ctx) (void)hipSetDevice(index->ctx->device);
     delete index;
+} catch (...) {
 }
 
 size_t pcrs_index_len(const pcrs_index *index) { return index ? index->m : 0; }
 
-int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]) {
+int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]) try {
     if (!index || !stats) return PCRS_ERR_INVALID_ARG;
     if (index->stats_dev) {
         pcrs_ctx *ctx = index->ctx;
@@ -346,12 +380,14 @@ int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]) {
     }
     for (int i = 0; i < 3; ++i) stats[i] = index->stats[i];
     return PCRS_OK;
+} catch (...) {
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------- knn
 
 int pcrs_knn_batch_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
-                       size_t n, uint32_t k, uint32_t *didx, float *ddist, uint32_t *dcount) {
+                       size_t n, uint32_t k, uint32_t *didx, float *ddist, uint32_t *dcount) try {
     if (!index) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -373,10 +409,12 @@ int pcrs_knn_batch_dev(pcrs_index *index, const float *dqx, const float *dqy, co
     o.count = dcount;
     o.k = k;
     return run_query(index, q, o, k);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 int pcrs_knn_batch(pcrs_index *index, const float *qx, const float *qy, const float *qz, size_t n,
-                   uint32_t k, uint32_t *idx, float *dist, uint32_t *count) {
+                   uint32_t k, uint32_t *idx, float *dist, uint32_t *count) try {
     if (!index) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -399,10 +437,12 @@ int pcrs_knn_batch(pcrs_index *index, const float *qx, const float *qy, const fl
     if (count) PCRS_TRY(download(ctx, count, dcount.p, n * sizeof(uint32_t)));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
-                          size_t n, float radius, uint32_t *dcount) {
+                          size_t n, float radius, uint32_t *dcount) try {
     if (!index || !dcount) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -421,13 +461,15 @@ int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy,
     }
     return pcrs_launch_radius_count(ctx, index->x, index->y, index->z, index->m, dqx, dqy, dqz, n,
                                     radius, dcount);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 // radius_outlier.rs:4-18 on device columns: grid with cells of the radius, one counting walk,
 // mask.  dcount (nullable) receives the per-point neighbour counts.
 int pcrs_radius_outlier_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
                             size_t n, float radius, size_t min_neighbors, uint8_t *dkeep,
-                            uint32_t *dcount, size_t *n_keep) {
+                            uint32_t *dcount, size_t *n_keep) try {
     PCRS_TRY(bind_device(ctx));
     if (n_keep) *n_keep = 0;
     if (n == 0) return PCRS_OK;
@@ -479,11 +521,13 @@ int pcrs_radius_outlier_dev(pcrs_ctx *ctx, const float *dx, const float *dy, con
     }
     pcrs_index_destroy(ix);
     return rc;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_radius_outlier(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                         float radius, size_t min_neighbors, uint8_t *keep, uint32_t *count,
-                        size_t *n_keep) {
+                        size_t *n_keep) try {
     PCRS_TRY(bind_device(ctx));
     if (n_keep) *n_keep = 0;
     if (n == 0) return PCRS_OK;
@@ -503,10 +547,12 @@ int pcrs_radius_outlier(pcrs_ctx *ctx, const float *x, const float *y, const flo
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (n_keep) *n_keep = kept;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const float *qz,
-                      size_t n, float radius, uint32_t *count) {
+                      size_t n, float radius, uint32_t *count) try {
     if (!index || !count) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -521,11 +567,13 @@ int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const
     PCRS_TRY(download(ctx, count, dcount.p, n * sizeof(uint32_t)));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 int pcrs_voxel_downsample_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
                               size_t n, float voxel_size, float *dout_x, float *dout_y,
-                              float *dout_z, size_t *n_out) {
+                              float *dout_z, size_t *n_out) try {
     PCRS_TRY(bind_device(ctx));
     if (!n_out) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     *n_out = 0;
@@ -536,11 +584,13 @@ int pcrs_voxel_downsample_dev(pcrs_ctx *ctx, const float *dx, const float *dy, c
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
     return pcrs_launch_voxel_downsample(ctx, dx, dy, dz, n, voxel_size, dout_x, dout_y, dout_z,
                                         n_out);
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                           float voxel_size, float *out_x, float *out_y, float *out_z,
-                          size_t *n_out) {
+                          size_t *n_out) try {
     PCRS_TRY(bind_device(ctx));
     if (!n_out) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     *n_out = 0;
@@ -565,12 +615,14 @@ int pcrs_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const f
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = nv;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_ransac_plane_samples_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
                                   size_t n, const uint32_t *dsamples, size_t n_samples,
                                   float distance_threshold, float model[4], uint8_t *dinlier_mask,
-                                  size_t *n_inliers, uint64_t *best_count) {
+                                  size_t *n_inliers, uint64_t *best_count) try {
     PCRS_TRY(bind_device(ctx));
     if (!model || !n_inliers) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     if (n && (!dx || !dy || !dz || !dinlier_mask))
@@ -578,12 +630,14 @@ int pcrs_ransac_plane_samples_dev(pcrs_ctx *ctx, const float *dx, const float *d
     if (n_samples && !dsamples) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null samples");
     return pcrs_launch_ransac_plane(ctx, dx, dy, dz, n, dsamples, n_samples, distance_threshold,
                                     model, dinlier_mask, n_inliers, best_count);
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_ransac_plane_samples(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                               size_t n, const uint32_t *samples, size_t n_samples,
                               float distance_threshold, float model[4], uint8_t *inlier_mask,
-                              size_t *n_inliers, uint64_t *best_count) {
+                              size_t *n_inliers, uint64_t *best_count) try {
     PCRS_TRY(bind_device(ctx));
     if (!model || !n_inliers) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     if (n && (!x || !y || !z || !inlier_mask))
@@ -603,12 +657,14 @@ int pcrs_ransac_plane_samples(pcrs_ctx *ctx, const float *x, const float *y, con
     if (n) PCRS_TRY(download(ctx, inlier_mask, dmask.p, n));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_euclidean_cluster_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
                                size_t n, float distance_threshold, size_t min_size,
                                size_t max_size, uint32_t *doffsets, uint32_t *dindices,
-                               size_t *n_clusters, size_t *n_indices) {
+                               size_t *n_clusters, size_t *n_indices) try {
     PCRS_TRY(bind_device(ctx));
     if (!n_clusters) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     *n_clusters = 0;
@@ -621,11 +677,13 @@ int pcrs_euclidean_cluster_dev(pcrs_ctx *ctx, const float *dx, const float *dy, 
                                            max_size, doffsets, dindices, n_clusters, &ni));
     if (n_indices) *n_indices = ni;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                            float distance_threshold, size_t min_size, size_t max_size,
-                           uint32_t *offsets, uint32_t *indices, size_t *n_clusters) {
+                           uint32_t *offsets, uint32_t *indices, size_t *n_clusters) try {
     PCRS_TRY(bind_device(ctx));
     if (!n_clusters || !offsets) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     *n_clusters = 0;
@@ -649,6 +707,8 @@ int pcrs_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y, const 
     }
     *n_clusters = nc;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 // -------------------------------------------------------------------------- SOR and normals
@@ -663,7 +723,7 @@ static int check_range(pcrs_index *index, size_t q_begin, size_t q_count) {
 
 int pcrs_sor_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k_sor,
                          uint32_t k_normals, const float viewpoint[3], float *dmean, float *dnx,
-                         float *dny, float *dnz) {
+                         float *dny, float *dnz) try {
     if (!index) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -701,9 +761,11 @@ int pcrs_sor_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint
         if (k_normals > kneed) kneed = k_normals;
     }
     return run_query(index, q, o, kneed);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
-int pcrs_index_slot_bounds(pcrs_index *index, uint32_t parts, size_t *bounds) {
+int pcrs_index_slot_bounds(pcrs_index *index, uint32_t parts, size_t *bounds) try {
     if (!index) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -714,11 +776,13 @@ int pcrs_index_slot_bounds(pcrs_index *index, uint32_t parts, size_t *bounds) {
         return PCRS_OK;
     }
     return pcrs_grid_slot_bounds(index, parts, bounds);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 int pcrs_sor_normals_slots_dev(pcrs_index *index, size_t slot_begin, size_t slot_count,
                                uint32_t k_sor, uint32_t k_normals, const float viewpoint[3],
-                               uint32_t *dpoint, float *dmean, float *dnx, float *dny, float *dnz) {
+                               uint32_t *dpoint, float *dmean, float *dnx, float *dny, float *dnz) try {
     if (!index) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = index->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -769,38 +833,48 @@ int pcrs_sor_normals_slots_dev(pcrs_index *index, size_t slot_begin, size_t slot
         if (k_normals > kneed) kneed = k_normals;
     }
     return run_query(index, q, o, kneed);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 int pcrs_scatter_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dpoint, size_t n,
-                         float *dout) {
+                         float *dout) try {
     PCRS_TRY(bind_device(ctx));
     if (n && (!dvalues || !dpoint || !dout))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     return pcrs_launch_scatter_perm(ctx, dvalues, dpoint, n, dout);
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_sor_mean_dist_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
-                           float *dmean) {
+                           float *dmean) try {
     if (!dmean) return PCRS_ERR_INVALID_ARG;
     return pcrs_sor_normals_dev(index, q_begin, q_count, k, 0, nullptr, dmean, nullptr, nullptr,
                                 nullptr);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 int pcrs_normals_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
-                     const float viewpoint[3], float *dnx, float *dny, float *dnz) {
+                     const float viewpoint[3], float *dnx, float *dny, float *dnz) try {
     if (!dnx || !dny || !dnz) return PCRS_ERR_INVALID_ARG;
     return pcrs_sor_normals_dev(index, q_begin, q_count, 0, k, viewpoint, nullptr, dnx, dny, dnz);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
 int pcrs_sor_threshold_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul, float *thr,
-                           int *has_finite) {
+                           int *has_finite) try {
     PCRS_TRY(bind_device(ctx));
     if (!thr || !has_finite) return PCRS_ERR_INVALID_ARG;
     return pcrs_sor_threshold_impl(ctx, dmean, n, std_mul, thr, has_finite);
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_sor_mask_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float thr, uint8_t *dkeep,
-                      size_t *n_keep) {
+                      size_t *n_keep) try {
     PCRS_TRY(bind_device(ctx));
     if (n_keep) *n_keep = 0;
     if (n == 0) return PCRS_OK;
@@ -822,6 +896,8 @@ int pcrs_sor_mask_dev(pcrs_ctx *ctx, const float *dmean, size_t n, float thr, ui
         *n_keep = (size_t)*hcount;
     }
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 // statistical_outlier.rs:43-66 without leaving the device between the statistics and the mask:
@@ -866,7 +942,7 @@ static void select_finish(const SelectPending &pend, float *thr, int *has_finite
 
 int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
                         const float *dmean, size_t n, uint8_t *dkeep, float *thr, int *has_finite,
-                        size_t *n_keep) {
+                        size_t *n_keep) try {
     PCRS_TRY(bind_device(ctx));
     if (thr) *thr = std::numeric_limits<float>::quiet_NaN();
     if (has_finite) *has_finite = 0;
@@ -879,13 +955,15 @@ int pcrs_sor_select_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, flo
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     select_finish(pend, thr, has_finite, n_keep);
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 // The same three launches with the library's static device array as work space and the results
 // left on the device: no allocation, no release, no synchronisation (see pcrs_hip.h).
 int pcrs_sor_select_static_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, float std_mul,
                                const float *dmean, size_t n, uint8_t *dkeep,
-                               pcrs_sor_select_result *dresult) {
+                               pcrs_sor_select_result *dresult) try {
     PCRS_TRY(bind_device(ctx));
     if (!dresult || (n_all && !dmean_all) || (n && (!dmean || !dkeep)))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
@@ -906,12 +984,14 @@ int pcrs_sor_select_static_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_a
     else
         PCRS_HIP_CHECK(ctx, hipMemsetAsync(dcount, 0, sizeof(*dcount), ctx->stream));
     return pcrs_launch_select_result(ctx, sc, dcount, dresult);
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                      uint32_t k_sor, float std_mul, uint32_t k_normals, const float viewpoint[3],
                      uint8_t *keep, size_t *n_keep, float *thr_out, float *nx, float *ny,
-                     float *nz) {
+                     float *nz) try {
     PCRS_TRY(bind_device(ctx));
     const bool want_sor = keep != nullptr;
     const bool want_n = nx || ny || nz;
@@ -1004,10 +1084,12 @@ int pcrs_sor_normals(pcrs_ctx *ctx, const float *x, const float *y, const float 
         if (n_keep) *n_keep = kept;  // no finite mean: every keep[i] is 0 (:49-51)
     }
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n, uint32_t k,
-             float std_mul, uint8_t *keep, size_t *n_keep, float *thr_out, float *mean_out) {
+             float std_mul, uint8_t *keep, size_t *n_keep, float *thr_out, float *mean_out) try {
     if (!keep && n) return PCRS_ERR_INVALID_ARG;
     if (n == 0) {
         if (n_keep) *n_keep = 0;
@@ -1058,36 +1140,43 @@ int pcrs_sor(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size
         if (n_keep) *n_keep = kept;
     }
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
-                 uint32_t k, const float viewpoint[3], float *nx, float *ny, float *nz) {
+                 uint32_t k, const float viewpoint[3], float *nx, float *ny, float *nz) try {
     if (!nx || !ny || !nz || !viewpoint) return PCRS_ERR_INVALID_ARG;
     return pcrs_sor_normals(ctx, x, y, z, n, 0, 0.0f, k, viewpoint, nullptr, nullptr, nullptr, nx,
                             ny, nz);
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 // ------------------------------------------------------------------------------ registration
 
 void pcrs_compose(const float ra[9], const float ta[3], const float rb[9], const float tb[3],
-                  float rout[9], float tout[3]) {
+                  float rout[9], float tout[3]) try {
     pcrs_host_compose(ra, ta, rb, tb, rout, tout);
+} catch (...) {
 }
 
 int pcrs_apply_transform_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
                              size_t n, const float rotation[9], const float translation[3],
-                             float *dox, float *doy, float *doz) {
+                             float *dox, float *doy, float *doz) try {
     PCRS_TRY(bind_device(ctx));
     if (!rotation || !translation) return PCRS_ERR_INVALID_ARG;
     if (n == 0) return PCRS_OK;
     if (!dx || !dy || !dz || !dox || !doy || !doz)
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
     return pcrs_launch_transform(ctx, dx, dy, dz, n, rotation, translation, dox, doy, doz);
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_apply_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                          const float rotation[9], const float translation[3], float *ox,
-                         float *oy, float *oz) {
+                         float *oy, float *oz) try {
     PCRS_TRY(bind_device(ctx));
     if (n == 0) return PCRS_OK;
     if (!x || !y || !z || !ox || !oy || !oz || !rotation || !translation)
@@ -1104,6 +1193,8 @@ int pcrs_apply_transform(pcrs_ctx *ctx, const float *x, const float *y, const fl
     PCRS_TRY(download(ctx, oz, dz.p, n * sizeof(float)));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 }  // extern "C"
@@ -1204,7 +1295,7 @@ extern "C" {
 
 int pcrs_find_correspondences_dev(pcrs_index *target, const float *dsx, const float *dsy,
                                   const float *dsz, size_t n, float max_distance,
-                                  uint32_t *dtgt_idx, float *ddist, size_t *n_corr) {
+                                  uint32_t *dtgt_idx, float *ddist, size_t *n_corr) try {
     if (!target) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = target->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -1223,11 +1314,13 @@ int pcrs_find_correspondences_dev(pcrs_index *target, const float *dsx, const fl
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (n_corr) *n_corr = (size_t)h[0];
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(target ? target->ctx : nullptr);
 }
 
 int pcrs_find_correspondences(pcrs_index *target, const float *sx, const float *sy,
                               const float *sz, size_t n, float max_distance, uint32_t *tgt_idx,
-                              float *dist, size_t *n_corr) {
+                              float *dist, size_t *n_corr) try {
     if (!target) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = target->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -1247,12 +1340,14 @@ int pcrs_find_correspondences(pcrs_index *target, const float *sx, const float *
     if (dist) PCRS_TRY(download(ctx, dist, dd.p, n * sizeof(float)));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(target ? target->ctx : nullptr);
 }
 
 int pcrs_icp_create_dev(pcrs_ctx *ctx, const float *dsx, const float *dsy, const float *dsz,
                         size_t n, const float *dtx, const float *dty, const float *dtz, size_t m,
                         const float *dtnx, const float *dtny, const float *dtnz, size_t n_normals,
-                        pcrs_icp **out) {
+                        pcrs_icp **out) try {
     if (!out) return PCRS_ERR_INVALID_ARG;
     *out = nullptr;
     PCRS_TRY(bind_device(ctx));
@@ -1281,11 +1376,13 @@ int pcrs_icp_create_dev(pcrs_ctx *ctx, const float *dsx, const float *dsy, const
     }
     *out = icp;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 int pcrs_icp_create(pcrs_ctx *ctx, const float *sx, const float *sy, const float *sz, size_t n,
                     const float *tx, const float *ty, const float *tz, size_t m, const float *tnx,
-                    const float *tny, const float *tnz, size_t n_normals, pcrs_icp **out) {
+                    const float *tny, const float *tnz, size_t n_normals, pcrs_icp **out) try {
     if (!out) return PCRS_ERR_INVALID_ARG;
     *out = nullptr;
     PCRS_TRY(bind_device(ctx));
@@ -1327,9 +1424,11 @@ int pcrs_icp_create(pcrs_ctx *ctx, const float *sx, const float *sy, const float
     }
     *out = icp;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
-void pcrs_icp_destroy(pcrs_icp *icp) {
+void pcrs_icp_destroy(pcrs_icp *icp) try {
     if (!icp) return;
     if (icp->ctx) {
         (void)hipSetDevice(icp->ctx->device);
@@ -1337,9 +1436,10 @@ void pcrs_icp_destroy(pcrs_icp *icp) {
     }
     pcrs_index_destroy(icp->target);
     delete icp;
+} catch (...) {
 }
 
-int pcrs_icp_reset(pcrs_icp *icp) {
+int pcrs_icp_reset(pcrs_icp *icp) try {
     if (!icp) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = icp->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -1349,9 +1449,11 @@ int pcrs_icp_reset(pcrs_icp *icp) {
     return pcrs_launch_transform(ctx, icp->sx, icp->sy, icp->sz, icp->n, rot, t,
                                  icp->cur[0].as<float>(), icp->cur[1].as<float>(),
                                  icp->cur[2].as<float>());
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
 }
 
-int pcrs_icp_accumulate(pcrs_icp *icp, int mode, float max_distance, double *sums) {
+int pcrs_icp_accumulate(pcrs_icp *icp, int mode, float max_distance, double *sums) try {
     if (!icp || !sums) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = icp->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -1373,9 +1475,11 @@ int pcrs_icp_accumulate(pcrs_icp *icp, int mode, float max_distance, double *sum
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(sums, pin, PCRS_ICP_NSUMS * sizeof(double));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
 }
 
-int pcrs_icp_solve(int mode, const double *sums, float rotation[9], float translation[3]) {
+int pcrs_icp_solve(int mode, const double *sums, float rotation[9], float translation[3]) try {
     if (!sums || !rotation || !translation) return PCRS_ERR_INVALID_ARG;
     if (mode == PCRS_ICP_POINT_TO_PLANE)
         pcrs_host_solve_plane(sums, rotation, translation);
@@ -1384,17 +1488,21 @@ int pcrs_icp_solve(int mode, const double *sums, float rotation[9], float transl
     else
         return PCRS_ERR_INVALID_ARG;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(nullptr);
 }
 
-int pcrs_icp_apply(pcrs_icp *icp, const float rotation[9], const float translation[3]) {
+int pcrs_icp_apply(pcrs_icp *icp, const float rotation[9], const float translation[3]) try {
     if (!icp || !rotation || !translation) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = icp->ctx;
     PCRS_TRY(bind_device(ctx));
     float *cx = icp->cur[0].as<float>(), *cy = icp->cur[1].as<float>(), *cz = icp->cur[2].as<float>();
     return pcrs_launch_transform(ctx, cx, cy, cz, icp->n, rotation, translation, cx, cy, cz);
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
 }
 
-int pcrs_icp_get_current(pcrs_icp *icp, float *x, float *y, float *z) {
+int pcrs_icp_get_current(pcrs_icp *icp, float *x, float *y, float *z) try {
     if (!icp) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = icp->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -1413,6 +1521,8 @@ int pcrs_icp_get_current(pcrs_icp *icp, float *x, float *y, float *z) {
     }
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
 }
 
 static void result_identity(pcrs_icp_result *r) {
@@ -1421,7 +1531,7 @@ static void result_identity(pcrs_icp_result *r) {
 }
 
 int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float tolerance,
-                 float max_correspondence_distance, pcrs_icp_result *out) {
+                 float max_correspondence_distance, pcrs_icp_result *out) try {
     if (!icp || !out) return PCRS_ERR_INVALID_ARG;
     pcrs_ctx *ctx = icp->ctx;
     PCRS_TRY(bind_device(ctx));
@@ -1509,12 +1619,14 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     out->converged = hs->converged ? 1 : 0;
     out->num_iterations = hs->num_iterations;
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
 }
 
 int pcrs_icp_register(pcrs_ctx *ctx, int mode, const float *sx, const float *sy, const float *sz, size_t n,
              const float *tx, const float *ty, const float *tz, size_t m, const float *tnx,
              const float *tny, const float *tnz, size_t n_normals, uint32_t max_iterations,
-             float tolerance, float max_correspondence_distance, pcrs_icp_result *out) {
+             float tolerance, float max_correspondence_distance, pcrs_icp_result *out) try {
     if (!out) return PCRS_ERR_INVALID_ARG;
     PCRS_TRY(bind_device(ctx));
     result_identity(out);
@@ -1534,6 +1646,8 @@ int pcrs_icp_register(pcrs_ctx *ctx, int mode, const float *sx, const float *sy,
     int rc = pcrs_icp_run(icp, mode, max_iterations, tolerance, max_correspondence_distance, out);
     pcrs_icp_destroy(icp);
     return rc;
+} catch (...) {
+    return pcrs_on_exception(ctx);
 }
 
 }  // extern "C"

@@ -60,6 +60,7 @@ void pcrs_timing_begin(pcrs_ctx *ctx);
 void pcrs_timing_end(pcrs_ctx *ctx);
 
 int pcrs_set_err(pcrs_ctx *ctx, int code, const char *fmt, ...);
+int pcrs_on_exception(pcrs_ctx *ctx) noexcept;
 // grows the context's device scratch / pinned staging; returns PCRS_OK or an error code
 int pcrs_ctx_scratch(pcrs_ctx *ctx, size_t bytes, void **out);
 int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out);
@@ -73,10 +74,12 @@ int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out);
 #define PCRS_HIP_CHECK(ctx, expr)                                                              \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess)                                                                  \
+        if (_e != hipSuccess) {                                                                \
+            (void)hipGetLastError(); /* the runtime keeps it: a later check must not see it */ \
             return pcrs_set_err((ctx), _e == hipErrorOutOfMemory ? PCRS_ERR_OOM : PCRS_ERR_HIP, \
                                 "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),          \
                                 __FILE__, __LINE__);                                           \
+        }                                                                                      \
     } while (0)
 
 // Owning device buffer; pooled when allocated through a context.
@@ -89,6 +92,7 @@ struct DevBuf {
         if (b == 0) b = 16;
         hipError_t e = hipMalloc(&p, b);
         if (e == hipSuccess) bytes = b;
+        else (void)hipGetLastError();  // do not leave the failure for a later check to find
         return e;
     }
     hipError_t alloc(pcrs_ctx *ctx, size_t b) {  // from the context's pool

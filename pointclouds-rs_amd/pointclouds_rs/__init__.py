@@ -11,8 +11,15 @@ error types:
     icp_point_to_point / icp_point_to_plane / apply_transform / IcpResult
                                                         .../registration.rs:4-109
 
-Functions of the reference module that are not on this path (voxel_downsample,
-passthrough_filter, ransac_plane, euclidean_cluster, file I/O) are not provided.
+and for the stages either side of it:
+
+    voxel_downsample(cloud, voxel_size)                 .../filters.rs:4-13
+    ransac_plane(cloud, distance_threshold, iterations) .../segmentation.rs:43-57
+    euclidean_cluster(cloud, distance_threshold, min_size, max_size)
+                                                        .../segmentation.rs:4-17
+    read_pcd / write_pcd                                .../io.rs:4-15
+
+passthrough_filter and the PLY / LAS readers of the reference module are not provided.
 Everything computes through libpcrs_hip.so; there is no CPU fallback.
 """
 from __future__ import annotations
@@ -143,22 +150,37 @@ def _require_cloud(c, name="cloud"):
         raise TypeError(f"argument '{name}': expected PointCloud")
 
 
+def _f32(v):
+    """A Python float as the PyO3 signature receives it: converted to f32 before the function
+    body runs, so a value beyond the f32 range is already infinite when it is checked."""
+    with np.errstate(over="ignore"):
+        return float(np.float32(float(v)))
+
+
+def _usize(v):
+    """PyO3's usize extraction: negative values fail at argument conversion, before any check
+    in the function body."""
+    v = int(v)
+    if v < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    return v
+
+
 def statistical_outlier_removal(cloud, k, std_mul):
     """crates/python/src/filters.rs:36-49 -> crates/filters/src/statistical_outlier.rs:4-69"""
     _require_cloud(cloud)
-    if k < 0:
-        raise OverflowError("can't convert negative int to unsigned")
-    std_mul = float(std_mul)
+    k = _usize(k)
+    std_mul = _f32(std_mul)
     if not math.isfinite(std_mul) or std_mul < 0.0:
         raise ValueError("std_mul must be >= 0 and finite")
-    keep, _, _, _ = hip.sor(cloud._x, cloud._y, cloud._z, int(k), std_mul)
+    keep, _, _, _ = hip.sor(cloud._x, cloud._y, cloud._z, k, std_mul)
     return cloud.select(np.nonzero(keep)[0])
 
 
 def voxel_downsample(cloud, voxel_size):
     """crates/python/src/filters.rs:4-13 -> crates/filters/src/voxel_downsample.rs:12-65"""
     _require_cloud(cloud)
-    voxel_size = float(voxel_size)
+    voxel_size = _f32(voxel_size)
     if not math.isfinite(voxel_size) or voxel_size <= 0.0:
         raise ValueError("voxel_size must be > 0 and finite")
     if cloud.is_empty():
@@ -277,14 +299,13 @@ def ransac_plane(cloud, distance_threshold, iterations):
 def radius_outlier_removal(cloud, radius, min_neighbors):
     """crates/python/src/filters.rs:51-64 -> crates/filters/src/radius_outlier.rs:4-18"""
     _require_cloud(cloud)
-    radius = float(radius)
+    radius = _f32(radius)
+    min_neighbors = _usize(min_neighbors)
     if not math.isfinite(radius) or radius <= 0.0:
         raise ValueError("radius must be > 0 and finite")
     if cloud.is_empty():
         return PointCloud()
-    if min_neighbors < 0:
-        raise OverflowError("can't convert negative int to unsigned")
-    keep, _, _ = hip.radius_outlier(cloud._x, cloud._y, cloud._z, radius, int(min_neighbors))
+    keep, _, _ = hip.radius_outlier(cloud._x, cloud._y, cloud._z, radius, min_neighbors)
     return cloud.select(np.nonzero(keep)[0])
 
 

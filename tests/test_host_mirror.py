@@ -45,6 +45,24 @@ def test_argument_validation_matches_reference():
         pc.icp_point_to_plane(c, c)  # registration.rs:67-72: target has no normals
     with pytest.raises(TypeError):
         pc.statistical_outlier_removal(np.zeros((2, 3)), 5, 1.0)
+    # the PyO3 signature takes f32: a value beyond its range is infinite when it is checked
+    # (filters.rs:5-10,40-46,54-61)
+    with pytest.raises(ValueError):
+        pc.statistical_outlier_removal(c, 5, 1e39)
+    with pytest.raises(ValueError):
+        pc.voxel_downsample(c, 1e39)
+    with pytest.raises(ValueError):
+        pc.radius_outlier_removal(c, 1e39, 3)
+    with pytest.raises(ValueError):
+        pc.voxel_downsample(c, 1e-60)  # rounds to 0.0f
+    # unsigned arguments fail at conversion, before the body's checks and early returns
+    empty = pc.PointCloud()
+    with pytest.raises(OverflowError):
+        pc.radius_outlier_removal(empty, 1.0, -1)
+    with pytest.raises(OverflowError):
+        pc.radius_outlier_removal(c, -1.0, -1)
+    with pytest.raises(OverflowError):
+        pc.statistical_outlier_removal(c, -1, float("nan"))
 
 
 def test_out_of_scope_functions_are_absent():

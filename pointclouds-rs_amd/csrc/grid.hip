@@ -398,6 +398,7 @@ struct CellArgs {
     GridGeom g;
     const uint32_t *cell_start;
     const float4 *spts;
+    const float *spts3;         // x, y, z of the same slots, 12 bytes apart (lane-per-query kernel)
     uint32_t nvalid;
     const float *rx, *ry, *rz;  // original columns (consumer gathers)
     // query addressing:
@@ -474,8 +475,46 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
     }
 }
 
+// The same walk over the 27-cell cube (R = 1) reading 12-byte points: f(point, slot).  The search
+// is bound by what its per-lane candidate loads move through the L1 (TA busy 75 % of the kernel),
+// and a candidate without its index is a quarter smaller.
+struct pcrs_p3 {
+    float x, y, z;
+};
+template <class F>
+__device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, int cz, F f) {
+    const GridGeom &g = a.g;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    const pcrs_p3 *base = reinterpret_cast<const pcrs_p3 *>(a.spts3);
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= g.nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= g.ny) continue;
+            const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+            const uint32_t s0 = a.cell_start[row + x0];
+            const uint32_t s1 = a.cell_start[row + x1 + 1];
+            const pcrs_p3 *pp = base + s0;
+            const pcrs_p3 *const pe = base + s1;
+            for (; pp + 3 < pe; pp += 4) {
+                const pcrs_p3 p0 = pp[0];
+                const pcrs_p3 p1 = pp[1];
+                const pcrs_p3 p2 = pp[2];
+                const pcrs_p3 p3 = pp[3];
+                const uint32_t s = (uint32_t)(pp - base);
+                f(p0, s);
+                f(p1, s + 1);
+                f(p2, s + 2);
+                f(p3, s + 3);
+            }
+            for (; pp < pe; ++pp) f(*pp, (uint32_t)(pp - base));
+        }
+    }
+}
+
 #ifndef PCRS_WPE
-#define PCRS_WPE 1
+#define PCRS_WPE 5
 #endif
 // Waves per SIMD the register allocator must leave room for: the walk is latency-bound, so
 // occupancy is worth more than a few spilled or rematerialised values.
@@ -537,8 +576,8 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 #pragma unroll
         for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
         const pcrs_f2 qxy = {qx, qy};
-        walk_cube(a, cx, cy, cz, [&](const float4 &p, const float4 *) {
-            const float d2 = sqdist_pk(qxy, qz, p);
+        walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t) {
+            const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
 #pragma unroll
             for (int s = K - 1; s > 0; --s) D[s] = __builtin_amdgcn_fmed3f(d2, D[s - 1], D[s]);
             D[0] = fminf(D[0], d2);
@@ -605,10 +644,10 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             for (int i = 0; i < K; ++i)
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
             uint32_t hits = 0;
-            walk_cube(a, cx, cy, cz, [&](const float4 &p, const float4 *at) {
-                const float d2 = sqdist_pk(qxy, qz, p);
+            walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t slot) {
+                const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
                 if (d2 <= tau) {
-                    if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = (uint32_t)(at - a.spts);
+                    if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = slot;
                     ++hits;
                 }
             });
@@ -626,7 +665,8 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             // insertion pass over ord[] then puts tie groups into index order.
             uint64_t used = 0;
             bool ties = false;
-            auto place_hit = [&](uint32_t j, const float4 &p) {
+            const pcrs_p3 *p3 = reinterpret_cast<const pcrs_p3 *>(a.spts3);
+            auto place_hit = [&](uint32_t j, const pcrs_p3 &p) {
                 const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
                 uint32_t rank = 0;
 #pragma unroll
@@ -639,16 +679,16 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             {
                 uint32_t j = 0;
                 for (; j + 3 < hits; j += 4) {
-                    const float4 p0 = a.spts[lst[j][threadIdx.x]];
-                    const float4 p1 = a.spts[lst[j + 1][threadIdx.x]];
-                    const float4 p2 = a.spts[lst[j + 2][threadIdx.x]];
-                    const float4 p3 = a.spts[lst[j + 3][threadIdx.x]];
-                    place_hit(j, p0);
-                    place_hit(j + 1, p1);
-                    place_hit(j + 2, p2);
-                    place_hit(j + 3, p3);
+                    const pcrs_p3 h0 = p3[lst[j][threadIdx.x]];
+                    const pcrs_p3 h1 = p3[lst[j + 1][threadIdx.x]];
+                    const pcrs_p3 h2 = p3[lst[j + 2][threadIdx.x]];
+                    const pcrs_p3 h3 = p3[lst[j + 3][threadIdx.x]];
+                    place_hit(j, h0);
+                    place_hit(j + 1, h1);
+                    place_hit(j + 2, h2);
+                    place_hit(j + 3, h3);
                 }
-                for (; j < hits; ++j) place_hit(j, a.spts[lst[j][threadIdx.x]]);
+                for (; j < hits; ++j) place_hit(j, p3[lst[j][threadIdx.x]]);
             }
             if (ties) {
                 auto key_at = [&](uint32_t o) {
@@ -758,6 +798,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
     constexpr int WAVES = GB_THREADS / 64;
     __shared__ uint32_t wl_slot[WAVES][64];
     __shared__ uint64_t wl_key[WAVES][64];
+    __shared__ float wl_px[WAVES][64], wl_py[WAVES][64], wl_pz[WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (a.skip && *a.skip) return;
     const uint32_t total = *a.qcount;
@@ -913,6 +954,17 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             }
             continue;
         }
+        // The neighbours' coordinates, one per lane and all in flight together: the lane that
+        // consumes the list would otherwise fetch them one dependent load after the other
+        if (COLLECT && out.nx) {
+            if ((uint32_t)lane < have) {
+                const uint32_t id = key_idx(wl_key[w][lane]);
+                wl_px[w][lane] = a.rx[id];
+                wl_py[w][lane] = a.ry[id];
+                wl_pz[w][lane] = a.rz[id];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         if (lane == 0) {
             KnnOut o2 = out;
             if (out.mean) {
@@ -934,8 +986,8 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             }
             if (COLLECT) {
                 o2.mean = nullptr;
-                consume(ListNbrs{&wl_key[w][0], a.rx, a.ry, a.rz}, have, true, (size_t)qi, qx, qy,
-                        qz, o2);
+                consume(StagedListNbrs{&wl_key[w][0], &wl_px[w][0], &wl_py[w][0], &wl_pz[w][0]}, have,
+                        true, (size_t)qi, qx, qy, qz, o2);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lists are reused next round
@@ -1247,6 +1299,17 @@ __global__ __launch_bounds__(GB_THREADS) void unpack_sorted_kernel(const float4 
     perm[i] = __float_as_uint(p.w);
 }
 
+// x, y, z of the sorted points as 12-byte records, once per build
+__global__ __launch_bounds__(GB_THREADS) void pack_xyz_kernel(const float4 *spts, uint32_t n,
+                                                              float *spts3) {
+    const uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = spts[i];
+    spts3[3 * (size_t)i] = p.x;
+    spts3[3 * (size_t)i + 1] = p.y;
+    spts3[3 * (size_t)i + 2] = p.z;
+}
+
 // Second half of the normal estimation: one thread per query turns the covariance sums left by
 // the search kernels into the oriented unit normal.
 __global__ __launch_bounds__(GB_THREADS) void normals_from_cov_kernel(
@@ -1539,6 +1602,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     ix->g = g;
     ix->ncell = ncell;
     ix->algo = PCRS_ALGO_GRID;
+    ix->spts3.release();  // made by the first search that wants it (pcrs_launch_knn_grid)
     return PCRS_OK;
 }
 
@@ -1546,6 +1610,7 @@ int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, ui
     pcrs_ctx *ctx = ix->ctx;
     if (ix->algo != PCRS_ALGO_GRID || ix->nvalid == 0)
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "index has no grid");
+    ix->spts3.release();  // the order inside the cells changes: the copy is rebuilt when needed
     hipLaunchKernelGGL(sort_cells_kernel, dim3((ix->ncell + GB_THREADS - 1) / GB_THREADS),
                        dim3(GB_THREADS), 0, ctx->stream, ix->cell_start.as<uint32_t>(), ix->ncell,
                        ix->spts.as<float4>());
@@ -1701,6 +1766,15 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.cell_start = ix->cell_start.as<uint32_t>();
     a.spts = ix->spts.as<float4>();
     a.nvalid = (uint32_t)ix->nvalid;
+    const bool nn_early = out_in.nn_idx && !out_in.idx && !out_in.dist && !out_in.count &&
+                          !out_in.mean && !out_in.nx;
+    if (!nn_early && !ix->spts3.p) {  // the index-free copy of the sorted points for k > 1 searches
+        PCRS_HIP_CHECK(ctx, ix->spts3.alloc(ctx, ix->nvalid * 3 * sizeof(float)));
+        hipLaunchKernelGGL(pack_xyz_kernel, dim3((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS)),
+                           dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(), (uint32_t)ix->nvalid,
+                           ix->spts3.as<float>());
+    }
+    a.spts3 = ix->spts3.as<float>();
     a.rx = ix->x;
     a.ry = ix->y;
     a.rz = ix->z;

@@ -216,6 +216,20 @@ struct ListNbrs {  // ascending keys of this query in memory
     }
 };
 
+struct StagedListNbrs {  // ascending keys of this query and their coordinates, by rank, in LDS
+    const uint64_t *key;
+    const float *px, *py, *pz;
+    template <class F>
+    __device__ __forceinline__ void for_each(uint32_t c, F f) const {
+        for (uint32_t j = 0; j < c; ++j) f(j, key[j], j);
+    }
+    __device__ __forceinline__ void fetch(uint64_t, uint32_t rank, float &x, float &y, float &z) const {
+        x = px[rank];
+        y = py[rank];
+        z = pz[rank];
+    }
+};
+
 // crates/normals/src/estimate.rs:139-238 — smallest-|eigenvalue| eigenvector of a symmetric 3x3,
 // f64 inside, written here for the device.
 __device__ inline void smallest_eigvec_3x3(float f00, float f01, float f02, float f11, float f12,

@@ -143,6 +143,8 @@ struct pcrs_index {
     uint32_t ncell = 0;
     DevBuf cell_start;   // uint32 [ncell + 1] slot ranges of the cells (x-fastest cell order)
     DevBuf spts;         // float4 [nvalid] points sorted by cell: (x, y, z, original index bits)
+    DevBuf spts3;        // float [3 * nvalid] the same points without the index (12-byte candidates:
+                         // the lane-per-query search is bound by the bytes its per-lane loads move)
     DevBuf fail_lists;   // two uint32 [nq] retry lists + stage counters, grown on demand
     // counters of the last query: read back lazily by pcrs_index_last_stats
     uint64_t stats[3] = {0, 0, 0};

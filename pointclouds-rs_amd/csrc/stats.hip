@@ -412,20 +412,89 @@ __global__ __launch_bounds__(64) void batch_composite_kernel(const Composite *co
 // leaves the binade (or was built for another one) is the first whose state fails the test: it
 // is found with a ballot, summed element by element with real f32 adds, and the scan restarts
 // behind it.
-template <int PASS, int W>
-__global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_t n,
+// STAGE (sums of up to ST_STAGE_CHUNKS chunks, one binade per chunk): the walker is one wave, so
+// every composite or element it has to fetch in the middle of the walk costs a full, unhidden
+// memory round trip -- two per binade crossing, some twenty crossings per sum.  It therefore
+// starts by copying all chunk composites into LDS and by fetching the elements of the chunks in
+// which the f64 prefix says a crossing falls (and their neighbours), everything in flight
+// together; the walk itself then runs out of LDS.  A chunk that was not foreseen is still read
+// from memory, so this changes when data arrives, never what is computed.
+constexpr uint32_t ST_STAGE_CHUNKS = 4096;
+constexpr int ST_PRE = 48;  // chunks whose elements are fetched ahead
+
+constexpr int ST_STAGE_THREADS = 1024;
+
+template <int PASS, int W, bool STAGE>
+__global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kernel(const float *mean, size_t n,
                                                         StatsScalars *sc, const Composite *comp,
                                                         const Composite *bcomp,
                                                         uint32_t chunk_begin, uint32_t nchunks,
-                                                        bool last, float std_mul) {
+                                                        bool last, float std_mul,
+                                                        const double *cpre) {
     // walks the chunks [chunk_begin, nchunks); the state crosses launches in sc->run
     constexpr int G = 4;
     constexpr uint32_t BATCH = 64u * G;
     static_assert(ST_PER_LANE == 4, "the element-wise path moves one float4 per lane");
+    static_assert(!STAGE || W == 1, "staging holds one composite per chunk");
     __shared__ float4 elems[64];
+    __shared__ Composite scomp[STAGE ? ST_STAGE_CHUNKS : 1];
+    __shared__ float4 pre_elems[STAGE ? ST_PRE : 1][64];
+    __shared__ uint32_t pre_chunk[STAGE ? 64 : 1];
     const int lane = threadIdx.x;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
     float s = chunk_begin ? sc->run : 0.0f;  // uniform across the wave
+    if constexpr (STAGE) {
+        // Staging is done by the whole block (ST_STAGE_THREADS threads: every load of a phase in
+        // flight at once); the walk that follows is the first wave's alone.
+        __shared__ uint32_t npre_s;
+        const uint32_t tid = threadIdx.x, nth = blockDim.x;
+        const uint32_t nloc = nchunks - chunk_begin;
+        // composites and the binade of every chunk's f64 prefix (kept in the composite's spare word)
+        for (uint32_t i = tid; i < nloc; i += nth) {
+            Composite c = comp[chunk_begin + i];
+            c.pad = (uint32_t)binade_of((float)cpre[chunk_begin + i]);
+            scomp[i] = c;
+        }
+        if (tid < 64u) pre_chunk[tid] = 0xFFFFFFFFu;
+        __syncthreads();
+        if (tid < 64u) {
+            uint32_t np = 0;
+            const unsigned long long lt = (1ull << tid) - 1ull;
+            for (uint32_t b0 = 0; b0 < nloc; b0 += 64u) {
+                const uint32_t c = b0 + tid;
+                bool cross = false;
+                if (c < nloc) {
+                    // a crossing inside chunk c, or inside a neighbour (the f32 sum drifts off the
+                    // prefix)
+                    const uint32_t lo = c ? c - 1u : 0u, hi = c + 2u < nloc ? c + 2u : nloc - 1u;
+                    const int e0 = (int)scomp[lo].pad, e1 = (int)scomp[hi].pad;
+                    cross = e0 != e1 || e0 == ST_NO_BINADE;
+                }
+                const unsigned long long m = __ballot(cross);
+                if (cross) {
+                    const uint32_t at = np + (uint32_t)__popcll(m & lt);
+                    if (at < (uint32_t)ST_PRE) pre_chunk[at] = chunk_begin + c;
+                }
+                np += (uint32_t)__popcll(m);
+            }
+            if (tid == 0) npre_s = np < (uint32_t)ST_PRE ? np : (uint32_t)ST_PRE;
+        }
+        __syncthreads();
+        const uint32_t npre = npre_s;
+        for (uint32_t t = tid; t < npre * 64u; t += nth) {
+            const uint32_t p = t >> 6, l = t & 63u;
+            bool fin;
+            const size_t e0 = (size_t)pre_chunk[p] * ST_CHUNK + l * ST_PER_LANE;
+            float4 v;
+            v.x = stat_element<PASS>(mean, n, e0 + 0, mu, &fin);
+            v.y = stat_element<PASS>(mean, n, e0 + 1, mu, &fin);
+            v.z = stat_element<PASS>(mean, n, e0 + 2, mu, &fin);
+            v.w = stat_element<PASS>(mean, n, e0 + 3, mu, &fin);
+            pre_elems[p][l] = v;
+        }
+        __syncthreads();
+        if (tid >= 64u) return;
+    }
     // the composites of the next batch are requested while the current one is being scanned
     auto load_batch = [&](uint32_t base, Composite (&dst)[G][W]) {
 #pragma unroll
@@ -436,7 +505,12 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
                 dst[k][j].a0 = dst[k][j].a1 = 0;
                 dst[k][j].e = ST_NO_BINADE;
                 dst[k][j].pad = 0;
-                if (ci < nchunks) dst[k][j] = comp[(size_t)ci * W + j];
+                if (ci < nchunks) {
+                    if constexpr (STAGE)
+                        dst[k][j] = scomp[ci - chunk_begin];
+                    else
+                        dst[k][j] = comp[(size_t)ci * W + j];
+                }
             }
         }
     };
@@ -580,7 +654,16 @@ __global__ __launch_bounds__(64) void stats_walk_kernel(const float *mean, size_
             if (first_bad < lim) {
                 // element-by-element f32 adds over this chunk (lane-major element order)
                 const uint32_t bad_chunk = base + first_bad;
-                const float4 mine4 = load_elements(bad_chunk);
+                float4 mine4;
+                bool staged = false;
+                if constexpr (STAGE) {
+                    const unsigned long long hit = __ballot(pre_chunk[lane] == bad_chunk);
+                    if (hit) {
+                        mine4 = pre_elems[__builtin_ctzll(hit)][lane];
+                        staged = true;
+                    }
+                }
+                if (!staged) mine4 = load_elements(bad_chunk);
                 // through shared memory: every lane reads all 256 values back (broadcast reads)
                 // and runs the same chain of adds
                 elems[lane] = mine4;
@@ -672,8 +755,12 @@ static void run_pass(pcrs_ctx *ctx, int W, const float *dmean, size_t n, StatsSc
                            ctx->stream, dmean, n, sc, csum, comp, 0u, nchunks);
         hipLaunchKernelGGL((batch_composite_kernel<1>), dim3((nchunks + kBatch - 1) / kBatch),
                            dim3(64), 0, ctx->stream, comp, bcomp, 0u, nchunks);
-        hipLaunchKernelGGL((stats_walk_kernel<PASS, 1>), dim3(1), dim3(64), 0, ctx->stream, dmean, n,
-                           sc, comp, bcomp, 0u, nchunks, true, std_mul);
+        if (nchunks <= ST_STAGE_CHUNKS)
+            hipLaunchKernelGGL((stats_walk_kernel<PASS, 1, true>), dim3(1), dim3(ST_STAGE_THREADS), 0, ctx->stream,
+                               dmean, n, sc, comp, bcomp, 0u, nchunks, true, std_mul, csum);
+        else
+            hipLaunchKernelGGL((stats_walk_kernel<PASS, 1, false>), dim3(1), dim3(64), 0, ctx->stream,
+                               dmean, n, sc, comp, bcomp, 0u, nchunks, true, std_mul, csum);
         return;
     }
     // Before element i the f32 sum s and the exact prefix p obey p / (1 + i 2^-24) <= s <=
@@ -688,8 +775,8 @@ static void run_pass(pcrs_ctx *ctx, int W, const float *dmean, size_t n, StatsSc
                            ctx->stream, dmean, n, sc, csum, comp, c0, c1);
         hipLaunchKernelGGL((batch_composite_kernel<4>), dim3((c1 - c0 + kBatch - 1) / kBatch),
                            dim3(64), 0, ctx->stream, comp, bcomp, c0, c1);
-        hipLaunchKernelGGL((stats_walk_kernel<PASS, 4>), dim3(1), dim3(64), 0, ctx->stream, dmean, n,
-                           sc, comp, bcomp, c0, c1, c1 == nchunks, std_mul);
+        hipLaunchKernelGGL((stats_walk_kernel<PASS, 4, false>), dim3(1), dim3(64), 0, ctx->stream,
+                           dmean, n, sc, comp, bcomp, c0, c1, c1 == nchunks, std_mul, csum);
     }
 }
 

@@ -163,6 +163,10 @@ int run_query(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kne
     ix->stats_dev = nullptr;
     if (ix->algo == PCRS_ALGO_GRID) return pcrs_launch_knn_grid(ix, q, out, kneed);
     ix->stats[2] = q.nq;
+    q.xform_fused = false;
+    if (q.xform)  // a pending increment of the queries: the brute-force kernel does not apply it
+        PCRS_TRY(pcrs_launch_transform_state(ix->ctx, q.wx, q.wy, q.wz, q.nq,
+                                             reinterpret_cast<const IcpLoopState *>(q.xform)));
     return pcrs_launch_knn_bf(ix->ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, nullptr, nullptr,
                               0);
 }
@@ -1227,19 +1231,29 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
                           const float *cy, const float *cz, size_t n, const float *tnx,
                           const float *tny, const float *tnz, float max_d, uint32_t *nn_idx,
                           float *nn_d2, double *dsums, uint32_t *tgt_out, float *dist_out,
-                          const IcpTail &tail = IcpTail(), bool coherent = false) {
+                          const IcpTail &tail = IcpTail(), bool coherent = false,
+                          float *const *writable = nullptr, unsigned retry_hint = 0,
+                          const uint32_t **fail_count_dev = nullptr) {
     KnnQuery q;
     q.qx = cx;
     q.qy = cy;
     q.qz = cz;
     q.nq = n;
     q.coherent = coherent;
+    q.retry_blocks_hint = retry_hint;
+    if (writable && tail.state) {  // the increment of the previous iteration is still to be applied
+        q.xform = tail.state;
+        q.wx = writable[0];
+        q.wy = writable[1];
+        q.wz = writable[2];
+    }
     if (tail.state) q.skip_flag = &tail.state->done;
     if (max_d >= 0.0f) q.useful_distance = max_d;  // NaN or negative: no bound
     KnnOut o;
     o.nn_idx = nn_idx;
     o.nn_d2 = nn_d2;
     PCRS_TRY(run_query(target, q, o, 1));
+    if (fail_count_dev) *fail_count_dev = q.fail_count_dev;
     return pcrs_launch_icp_reduce(ctx, mode, cx, cy, cz, n, target->x, target->y, target->z, tnx,
                                   tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums, tail);
 }
@@ -1551,8 +1565,11 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     // The loop state lives on the device (icp_tail_step carries icp.rs:147-188), so the host only
     // looks at it every few iterations; iterations queued behind the end of the loop are no-ops.
     void *pin = nullptr;
-    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState), &pin));
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState) + 64, &pin));
     IcpLoopState *hs = reinterpret_cast<IcpLoopState *>(pin);
+    uint32_t *hfail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pin) +
+                                                   ((sizeof(IcpLoopState) + 15) & ~(size_t)15));
+    *hfail = 0;
     std::memset(hs, 0, sizeof(*hs));
     hs->cum_r[0] = hs->cum_r[4] = hs->cum_r[8] = 1.0f;
     hs->inc_r[0] = hs->inc_r[4] = hs->inc_r[8] = 1.0f;
@@ -1575,13 +1592,19 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     tail.seq_scalars = icp->seq_work.p;
     tail.seq_work = reinterpret_cast<char *>(icp->seq_work.p) + icp->seq_scalars_bytes;
     tail.seq_work_bytes = icp->seq_work.bytes - icp->seq_scalars_bytes;
+    float *const cur_w[3] = {cx, cy, cz};
+    unsigned retry_hint = 0;                 // retry-stage grid of the searches (0 = worst case)
+    const uint32_t *fail_count_dev = nullptr;  // the last search's "left after stage 1" counter
+    // icp.rs:186 (current <- increment(current)) is not a launch of its own: the search of the
+    // next iteration applies the pending increment as it loads its queries
     auto iteration = [&](uint32_t it) {
         tail.d2seq = icp->d2seq.as<float>() + (size_t)(it & 1u) * icp->n;
         return correspond_and_reduce(ctx, icp->target, mode, cx, cy, cz, icp->n, icp->tnx, icp->tny,
                                      icp->tnz, max_correspondence_distance,
                                      icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
                                      icp->sums.as<double>(), nullptr, nullptr, tail,
-                                     icp->perm.p != nullptr);
+                                     icp->perm.p != nullptr, it > 0 ? cur_w : nullptr, retry_hint,
+                                     &fail_count_dev);
     };
     if (max_iterations == 0) {  // icp.rs:190-197: one metrics pass, identity transform
         tail.metrics_only = true;
@@ -1591,15 +1614,20 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     constexpr uint32_t kBatch = 4;
     for (uint32_t iter = 0; iter < max_iterations;) {
         const uint32_t nb = std::min(kBatch, max_iterations - iter);
-        for (uint32_t j = 0; j < nb; ++j) {
-            PCRS_TRY(iteration(iter + j));  // search, reduction and the tail of the iteration
-            PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));  // icp.rs:186
-        }
+        for (uint32_t j = 0; j < nb; ++j)
+            PCRS_TRY(iteration(iter + j));  // [pending increment,] search, reduction, tail
         iter += nb;
         PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));  // hs is pinned
+        if (fail_count_dev) PCRS_TRY(pcrs_launch_publish(ctx, fail_count_dev, hfail, sizeof(uint32_t)));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done) break;
+        // The retry stage reads its work from device memory, so its grid may be any size: what the
+        // last search left over (with room to double) instead of the worst case spares most of an
+        // empty launch once the clouds are nearly aligned.
+        if (fail_count_dev) retry_hint = std::max(64u, (*hfail + 1u) / 2u);
     }
+    // the increment of the last iteration (a no-op once the loop has ended on its own)
+    if (max_iterations > 0) PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));
     if (max_iterations == 0) {
         PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -428,7 +428,12 @@ struct CellArgs {
     uint32_t *fail_count;
     uint32_t kcert;         // neighbours that must be certified (<= K)
     uint32_t kcollect;      // neighbours whose identity is needed (pass 2), 0 = none
+    uint32_t *zero_me;      // first-stage kernels: 16 words to clear (the next search's counters)
     const uint32_t *skip;   // nullable device word: non-zero makes the launch a no-op
+    // 1-NN kernel, qmode 1: a rigid increment applied to each query as it is loaded and written
+    // back through wx/wy/wz (see KnnQuery::xform); null = queries are used as they are
+    const IcpLoopState *xform;
+    float *wx, *wy, *wz;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Queries come in
@@ -530,6 +535,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
     __shared__ uint32_t lst[COLLECT ? CAP : 1][GB_THREADS];  // slots of the hits, walk order
     __shared__ uint8_t ord[COLLECT ? CAP : 1][GB_THREADS];   // ord[r] = list position of rank r
 
+    if (a.zero_me && blockIdx.x == 0 && threadIdx.x < 16) a.zero_me[threadIdx.x] = 0u;
     if (a.skip && *a.skip) return;
     uint32_t total = a.nq;
     if (a.qmode >= 2) total = *a.qcount;
@@ -1056,6 +1062,7 @@ __global__ __launch_bounds__(GB_THREADS) void owned_write_kernel(const float4 *s
 constexpr int NN_SUB = 8;
 
 __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut out) {
+    if (a.zero_me && blockIdx.x == 0 && threadIdx.x < 16) a.zero_me[threadIdx.x] = 0u;
     if (a.skip && *a.skip) return;
     uint32_t total = a.nq;
     if (a.qmode == 2 || a.qmode == 4) total = *a.qcount;
@@ -1080,6 +1087,21 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
             qx = a.qx[qi];
             qy = a.qy[qi];
             qz = a.qz[qi];
+            if (a.xform) {
+                // the increment of the previous iteration (icp.rs:39-47,186), applied here instead
+                // of by a kernel of its own; every lane of the query computes the same point, one
+                // stores it for the kernels that follow
+                const float *r = a.xform->inc_r, *t = a.xform->inc_t;
+                const float px = qx, py = qy, pz = qz;
+                qx = ((r[0] * px + r[1] * py) + r[2] * pz) + t[0];
+                qy = ((r[3] * px + r[4] * py) + r[5] * pz) + t[1];
+                qz = ((r[6] * px + r[7] * py) + r[8] * pz) + t[2];
+                if (sub == 0) {
+                    a.wx[qi] = qx;
+                    a.wy[qi] = qy;
+                    a.wz[qi] = qz;
+                }
+            }
         }
         const bool qvalid = active && finite3(qx, qy, qz);
         const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
@@ -1744,11 +1766,22 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     // Lists longer than the register budget go to the brute-force kernel, which handles any k.
     if (keff > PCRS_KMAX_REG || keff == 0) {
         ix->stats[2] = q.nq;
+        q.xform_fused = false;
+        if (q.xform)  // a pending increment of the queries: the brute-force kernel does not apply it
+            PCRS_TRY(pcrs_launch_transform_state(ctx, q.wx, q.wy, q.wz, q.nq,
+                                                 reinterpret_cast<const IcpLoopState *>(q.xform)));
         return pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out, kneed, nullptr, nullptr,
                                   0);
     }
     const bool nn_only = out.nn_idx && !out.idx && !out.dist && !out.count && !out.mean && !out.nx;
     const uint32_t nq = (uint32_t)q.nq;
+    // A pending increment of the queries (KnnQuery::xform) is applied by the 1-NN kernel as it
+    // loads them, when that kernel reads the caller's columns directly; otherwise here, first.
+    const bool fuse_xform = q.xform && nn_only && !q.self && (q.coherent || nq < 32768u);
+    q.xform_fused = fuse_xform;
+    if (q.xform && !fuse_xform)
+        PCRS_TRY(pcrs_launch_transform_state(ctx, q.wx, q.wy, q.wz, q.nq,
+                                             reinterpret_cast<const IcpLoopState *>(q.xform)));
 
     // two retry lists (ping-pong) + stage counters
     const size_t list_elems = (size_t)nq + 64;
@@ -1758,8 +1791,16 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     }
     uint32_t *listA = ix->fail_lists.as<uint32_t>();
     uint32_t *listB = listA + list_elems;
-    uint32_t *counters = listB + list_elems;  // [0..3] failures after each cube stage, [4] owned
-    PCRS_HIP_CHECK(ctx, hipMemsetAsync(counters, 0, 16 * sizeof(uint32_t), ctx->stream));
+    if (!ix->counters.p) {
+        PCRS_HIP_CHECK(ctx, ix->counters.alloc(ctx, 32 * sizeof(uint32_t)));
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(ix->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
+        ix->counter_phase = 0;
+    }
+    // [0..3] failures after each cube stage, [4] owned; this search's set is zero (cleared by the
+    // search before it, or just now), and its first kernel clears the other set
+    uint32_t *counters = ix->counters.as<uint32_t>() + 16 * ix->counter_phase;
+    uint32_t *counters_next = ix->counters.as<uint32_t>() + 16 * (ix->counter_phase ^ 1);
+    ix->counter_phase ^= 1;
 
     CellArgs a{};
     a.g = ix->g;
@@ -1782,6 +1823,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.qy = q.qy;
     a.qz = q.qz;
     a.kcert = keff;
+    a.zero_me = counters_next;
     a.skip = q.skip_flag;
     a.useful_d2 = __builtin_inff();
     if (nn_only && q.useful_distance < __builtin_inff()) {
@@ -1881,9 +1923,19 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     }
     // the timing bracket covers the dominant kernel only (stage 1 over every query), so that it
     // can be set against the same kernel's duration in a profiler trace
+    if (fuse_xform) {
+        if (a.qmode != 1) return pcrs_set_err(ctx, PCRS_ERR_HIP, "internal: fused transform needs direct queries");
+        a.xform = reinterpret_cast<const IcpLoopState *>(q.xform);
+        a.wx = q.wx;
+        a.wy = q.wy;
+        a.wz = q.wz;
+    }
+    q.fail_count_dev = &counters[0];
     pcrs_timing_begin(ctx);
     launch(blocks1);
     pcrs_timing_end(ctx);
+    a.xform = nullptr;
+    a.zero_me = nullptr;
     const bool timing_was = ctx->timing;
     ctx->timing = false;  // the retry stages below are not separate measurements
 
@@ -1903,7 +1955,8 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         PCRS_DISPATCH_K(kb, PCRS_WAVE_CALL)
 #undef PCRS_WAVE_CALL
     };
-    const unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);
+    unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);
+    if (q.retry_blocks_hint) retry_blocks = std::min(retry_blocks, q.retry_blocks_hint);
     // one launch tries the cube half-widths 2, 4, 8 in turn for each failed query
     a.wave_radii[0] = 1;
     a.wave_radii[1] = 2;

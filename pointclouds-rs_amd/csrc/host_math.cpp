@@ -9,9 +9,11 @@ void pcrs_host_compose(const float ra[9], const float ta[3], const float rb[9], 
 }
 
 void pcrs_host_solve_plane(const double *sums, float rot[9], float t[3]) {
-    pcrs_math::solve_plane(sums, rot, t);
+    pcrs_math::Work w;
+    pcrs_math::solve_plane(w, sums, rot, t);
 }
 
 void pcrs_host_solve_point(const double *sums, float rot[9], float t[3]) {
-    pcrs_math::solve_point(sums, rot, t);
+    pcrs_math::Work w;
+    pcrs_math::solve_point(w, sums, rot, t);
 }

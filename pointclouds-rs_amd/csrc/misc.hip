@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void radius_count_kernel(const float *rx, cons
 // partials in block order.  No floating-point atomics, so the result is run-to-run identical.
 constexpr int ICP_THREADS = 256;
 
+__device__ __forceinline__ void icp_tail_step(pcrs_math::Work &w, int mode, const double *sums,
+                                              float n_source, float tolerance, bool metrics_only,
+                                              const float *exact_sum, IcpLoopState *st);
+
 template <int MODE>
 __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
     const float *cx, const float *cy, const float *cz, uint32_t n, const float *tx,
@@ -198,8 +202,9 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
 // What the host does between two iterations of the ICP loop (icp.rs:147-188), for one thread.
 // exact_sum (nullable): the left-to-right f32 sum of dist*dist in source order (icp.rs:277-281);
 // without it the rmse comes from the f64 tree sum, within ~1e-5 relative of the former.
-__device__ inline void icp_tail_step(int mode, const double *sums, float n_source, float tolerance,
-                                     bool metrics_only, const float *exact_sum, IcpLoopState *st) {
+__device__ __forceinline__ void icp_tail_step(pcrs_math::Work &w, int mode, const double *sums,
+                                              float n_source, float tolerance, bool metrics_only,
+                                              const float *exact_sum, IcpLoopState *st) {
     if (st->done) return;
     if (!metrics_only) st->num_iterations += 1u;
     if (!(sums[0] > 0.0)) {  // icp.rs:163-165
@@ -226,9 +231,9 @@ __device__ inline void icp_tail_step(int mode, const double *sums, float n_sourc
     st->prev_rmse = rmse;
     float r[9], t[3];
     if (mode == PCRS_ICP_POINT_TO_PLANE)
-        pcrs_math::solve_plane(sums, r, t);
+        pcrs_math::solve_plane(w, sums, r, t);
     else
-        pcrs_math::solve_point(sums, r, t);
+        pcrs_math::solve_point(w, sums, r, t);
     for (int i = 0; i < 9; ++i) st->inc_r[i] = r[i];
     for (int i = 0; i < 3; ++i) st->inc_t[i] = t[i];
     float cr[9], ct[3], nr[9], nt[3];
@@ -242,13 +247,18 @@ __device__ inline void icp_tail_step(int mode, const double *sums, float n_sourc
 
 // Stage 2: 32 groups of threads fold the block partials (group g takes blocks g, g+32, ... in
 // order), then 32 threads fold the groups in order: a fixed summation tree, a few microseconds.
-// With tail_here, thread 0 then runs the tail of the iteration on the fresh sums.
+// With tail_here, thread 0 then runs the tail of the iteration on the fresh sums.  (Folding this
+// stage into the last block of stage 1 was tried: the device-scope fence every block then needs
+// before it draws its ticket writes back the L2 of its XCD and cost 26 us per launch, three times
+// what this launch costs.)
 __global__ __launch_bounds__(1024) void icp_final_kernel(const double *partials, uint32_t nblocks,
                                                          double *sums, int mode, float n_source,
                                                          float tolerance, int metrics_only,
                                                          int tail_here, IcpLoopState *st) {
     if (st && st->done) return;
     __shared__ double grp[32][PCRS_ICP_NSUMS + 1];
+    __shared__ double total[PCRS_ICP_NSUMS];
+    __shared__ pcrs_math::Work work;  // the solver's arrays: LDS, so that the kernel needs no scratch
     const int i = threadIdx.x & 31, gidx = threadIdx.x >> 5;
     double v = 0.0;
     for (uint32_t b = gidx; b < nblocks; b += 32) v += partials[(size_t)b * PCRS_ICP_NSUMS + i];
@@ -257,14 +267,12 @@ __global__ __launch_bounds__(1024) void icp_final_kernel(const double *partials,
     if (threadIdx.x < PCRS_ICP_NSUMS) {
         double t = 0.0;
         for (int q = 0; q < 32; ++q) t += grp[q][threadIdx.x];
+        total[threadIdx.x] = t;
         sums[threadIdx.x] = t;
     }
-    if (st && tail_here) {
-        __threadfence_block();
-        __syncthreads();
-        if (threadIdx.x == 0)
-            icp_tail_step(mode, sums, n_source, tolerance, metrics_only != 0, nullptr, st);
-    }
+    __syncthreads();
+    if (st && tail_here && threadIdx.x == 0)
+        icp_tail_step(work, mode, total, n_source, tolerance, metrics_only != 0, nullptr, st);
 }
 
 }  // namespace pcrs
@@ -388,7 +396,8 @@ namespace pcrs {
 
 __global__ void icp_tail_kernel(int mode, const double *sums, float n_source, float tolerance,
                                 int metrics_only, const float *exact_sum, IcpLoopState *st) {
-    icp_tail_step(mode, sums, n_source, tolerance, metrics_only != 0, exact_sum, st);
+    __shared__ pcrs_math::Work work;
+    icp_tail_step(work, mode, sums, n_source, tolerance, metrics_only != 0, exact_sum, st);
 }
 
 // After a loop whose rmse values came from the f64 sums (tolerance <= 0: the convergence test
@@ -465,7 +474,7 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
         return PCRS_OK;
     }
     size_t blocks = (n + ICP_THREADS - 1) / ICP_THREADS;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 256) blocks = 256;  // one per CU: fewer partials for the single block of stage 2
     void *scratch = nullptr;
     int rc = pcrs_ctx_scratch(ctx, blocks * PCRS_ICP_NSUMS * sizeof(double), &scratch);
     if (rc != PCRS_OK) return rc;

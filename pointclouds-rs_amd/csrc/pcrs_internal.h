@@ -145,7 +145,11 @@ struct pcrs_index {
     DevBuf spts;         // float4 [nvalid] points sorted by cell: (x, y, z, original index bits)
     DevBuf spts3;        // float [3 * nvalid] the same points without the index (12-byte candidates:
                          // the lane-per-query search is bound by the bytes its per-lane loads move)
-    DevBuf fail_lists;   // two uint32 [nq] retry lists + stage counters, grown on demand
+    DevBuf fail_lists;   // two uint32 [nq] retry lists, grown on demand
+    // Two sets of 16 stage counters.  A search uses one set and its first kernel clears the
+    // other for the search after it, so no search starts with a fill command of its own.
+    DevBuf counters;
+    int counter_phase = 0;
     // counters of the last query: read back lazily by pcrs_index_last_stats
     uint64_t stats[3] = {0, 0, 0};
     const uint32_t *stats_dev = nullptr;  // device counters [4]: failures after cube stages 1-4
@@ -191,6 +195,18 @@ struct KnnQuery {
     // device word that, when non-zero, turns the whole search into a no-op (an ICP iteration
     // queued behind the end of its loop)
     const uint32_t *skip_flag = nullptr;
+    // 1-NN searches of an ICP loop: `xform` (device, an IcpLoopState) holds a rigid increment that
+    // is still to be applied to the queries; a search kernel that can do so applies it as it
+    // loads each query, writes the moved point back to wx/wy/wz (the query columns, writable) and
+    // reports it in xform_fused -- one launch less per iteration.
+    const void *xform = nullptr;
+    float *wx = nullptr, *wy = nullptr, *wz = nullptr;
+    mutable bool xform_fused = false;
+    // blocks for the retry stage (0 = sized for the worst case); the stage reads its work from
+    // device memory in a grid-stride loop, so any size is correct
+    unsigned retry_blocks_hint = 0;
+    // receives the device address of this search's "queries left after the first stage" counter
+    mutable const uint32_t *fail_count_dev = nullptr;
 };
 
 // ---- brute force (knn_bf.hip)

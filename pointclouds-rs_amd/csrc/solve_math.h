@@ -8,7 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
-#define PCRS_HD __host__ __device__
+// always inlined: a solver array whose address crosses a call stays in (scratch) memory
+#define PCRS_HD __host__ __device__ __attribute__((always_inline))
 
 namespace pcrs_math {
 
@@ -18,9 +19,19 @@ PCRS_HD inline void identity(float rot[9], float t[3]) {
     t[0] = t[1] = t[2] = 0.0f;
 }
 
+// Every array the solves index with a run-time subscript.  On the device such arrays would live
+// in scratch memory, and a kernel that needs scratch pays for it at every launch; there the
+// caller puts one Work into LDS.  The host keeps it on the stack.
+struct Work {
+    double A[6][6], L[6][6], M[6][7], b[6], x[6], y[6];                       // 6x6 system
+    double S[3][3], H[3][3], U[3][3], V[3][3], Vs[3][3], R[3][3], sv[3], nrm[3], u[3];  // 3x3 SVD
+    int ord[3];
+    bool have[3];
+};
+
 // Cholesky-Banachiewicz (row by row) factorisation and the two triangular solves.
-PCRS_HD inline bool cholesky6(const double A[6][6], const double b[6], double x[6]) {
-    double L[6][6];
+PCRS_HD inline bool cholesky6(Work &w, const double A[6][6], const double b[6], double x[6]) {
+    double (&L)[6][6] = w.L;
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
     for (int i = 0; i < 6; ++i) {
@@ -35,7 +46,7 @@ PCRS_HD inline bool cholesky6(const double A[6][6], const double b[6], double x[
             }
         }
     }
-    double y[6];
+    double (&y)[6] = w.y;
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
         for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
@@ -50,8 +61,8 @@ PCRS_HD inline bool cholesky6(const double A[6][6], const double b[6], double x[
 }
 
 // Gaussian elimination with partial pivoting (the reference's LU fallback).
-PCRS_HD inline bool lu6(const double A[6][6], const double b[6], double x[6]) {
-    double M[6][7];
+PCRS_HD inline bool lu6(Work &w, const double A[6][6], const double b[6], double x[6]) {
+    double (&M)[6][7] = w.M;
     for (int i = 0; i < 6; ++i) {
         for (int j = 0; j < 6; ++j) M[i][j] = A[i][j];
         M[i][6] = b[i];
@@ -81,8 +92,9 @@ PCRS_HD inline bool lu6(const double A[6][6], const double b[6], double x[6]) {
 }
 
 // One-sided (Hestenes) Jacobi SVD of a 3x3: A = U diag(s) V^T, s descending.
-PCRS_HD inline void svd3(const double Ain[3][3], double U[3][3], double s[3], double V[3][3]) {
-    double A[3][3];
+PCRS_HD inline void svd3(Work &w, const double Ain[3][3], double U[3][3], double s[3],
+                         double V[3][3]) {
+    double (&A)[3][3] = w.S;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) A[i][j] = Ain[i][j];
     for (int i = 0; i < 3; ++i)
@@ -114,10 +126,13 @@ PCRS_HD inline void svd3(const double Ain[3][3], double U[3][3], double s[3], do
             }
         if (off < 1e-15) break;
     }
-    double nrm[3];
+    double (&nrm)[3] = w.nrm;
     for (int j = 0; j < 3; ++j)
         nrm[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
-    int ord[3] = {0, 1, 2};
+    int (&ord)[3] = w.ord;
+    ord[0] = 0;
+    ord[1] = 1;
+    ord[2] = 2;
     for (int i = 0; i < 2; ++i)
         for (int j = i + 1; j < 3; ++j)
             if (nrm[ord[j]] > nrm[ord[i]]) {
@@ -125,8 +140,8 @@ PCRS_HD inline void svd3(const double Ain[3][3], double U[3][3], double s[3], do
                 ord[i] = ord[j];
                 ord[j] = tmp;
             }
-    double Vs[3][3];
-    bool have[3];
+    double (&Vs)[3][3] = w.Vs;
+    bool (&have)[3] = w.have;
     for (int c = 0; c < 3; ++c) {
         const int o = ord[c];
         s[c] = nrm[o];
@@ -141,7 +156,7 @@ PCRS_HD inline void svd3(const double Ain[3][3], double U[3][3], double s[3], do
     for (int c = 0; c < 3; ++c) {
         if (have[c]) continue;
         const int a = (c + 1) % 3, b = (c + 2) % 3;
-        double u[3];
+        double (&u)[3] = w.u;
         if (have[a] && have[b]) {
             u[0] = U[1][a] * U[2][b] - U[2][a] * U[1][b];
             u[1] = U[2][a] * U[0][b] - U[0][a] * U[2][b];
@@ -201,10 +216,11 @@ PCRS_HD inline void compose(const float ra[9], const float ta[3], const float rb
 }
 
 // icp_plane.rs:137-139,182-235 from the accumulated upper triangle of A^T A and A^T b.
-PCRS_HD inline void solve_plane(const double *sums, float rot[9], float t[3]) {
+PCRS_HD inline void solve_plane(Work &w, const double *sums, float rot[9], float t[3]) {
     identity(rot, t);
     if (!(sums[0] > 0.0)) return;
-    double A[6][6], b[6];
+    double (&A)[6][6] = w.A;
+    double (&b)[6] = w.b;
     int s = 2;
     for (int r = 0; r < 6; ++r)
         for (int c = r; c < 6; ++c) {
@@ -217,8 +233,8 @@ PCRS_HD inline void solve_plane(const double *sums, float rot[9], float t[3]) {
     for (int i = 0; i < 6; ++i) diag_max = fmax(diag_max, fabs(A[i][i]));
     const double lambda = 1e-6 * fmax(diag_max, 1e-12);
     for (int i = 0; i < 6; ++i) A[i][i] += lambda;
-    double x[6];
-    if (!cholesky6(A, b, x) && !lu6(A, b, x)) return;
+    double (&x)[6] = w.x;
+    if (!cholesky6(w, A, b, x) && !lu6(w, A, b, x)) return;
     const float alpha = (float)x[0], beta = (float)x[1], gamma = (float)x[2];
     t[0] = (float)x[3];
     t[1] = (float)x[4];
@@ -246,19 +262,23 @@ PCRS_HD inline void solve_plane(const double *sums, float rot[9], float t[3]) {
 }
 
 // icp.rs:210-270 from f64 sums: centroids, H = sum s t^T - n sbar tbar^T, Kabsch rotation.
-PCRS_HD inline void solve_point(const double *sums, float rot[9], float t[3]) {
+PCRS_HD inline void solve_point(Work &w, const double *sums, float rot[9], float t[3]) {
     identity(rot, t);
     const double n = sums[0];
     if (!(n > 0.0)) return;
-    double sbar[3], tbar[3], H[3][3];
+    double sbar[3], tbar[3];
+    double (&H)[3][3] = w.H;
     for (int a = 0; a < 3; ++a) {
         sbar[a] = sums[2 + a] / n;
         tbar[a] = sums[5 + a] / n;
     }
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) H[r][c] = sums[8 + r * 3 + c] - n * sbar[r] * tbar[c];
-    double U[3][3], sv[3], V[3][3], R[3][3];
-    svd3(H, U, sv, V);
+    double (&U)[3][3] = w.U;
+    double (&sv)[3] = w.sv;
+    double (&V)[3][3] = w.V;
+    double (&R)[3][3] = w.R;
+    svd3(w, H, U, sv, V);
     for (int pass = 0; pass < 2; ++pass) {
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)

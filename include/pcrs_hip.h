@@ -360,6 +360,41 @@ int pcrs_icp_get_current(pcrs_icp *icp, float *x, float *y, float *z);
 int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float tolerance,
                  float max_correspondence_distance, pcrs_icp_result *out);
 
+/* The same loop with the source split over several GPUs (one pcrs_icp per rank over its shard
+ * of the source and the whole target).  An iteration of icp.rs:147-188 is cut where the sums of
+ * the shards meet; the caller's collective runs between the two halves, and nothing in them
+ * waits for the device:
+ *
+ *   pcrs_icp_shard_begin(icp, n_source_total)
+ *   for it in 0 .. max_iterations:                     (queue several, then look at the state)
+ *     pcrs_icp_shard_accumulate_dev(icp, mode, max_d, it, dsums, &dd2)
+ *         search + reduction of this shard into dsums[PCRS_ICP_NSUMS] (device); *dd2 (nullable
+ *         argument) = device address of dist*dist of the shard's points in their input order
+ *         (icp.rs:279), owned by the handle and valid until iteration it + 2 is queued
+ *     all-gather of dsums (and of dd2 where the reference's own rmse is wanted) over the ranks
+ *     pcrs_icp_shard_update_dev(icp, mode, dsums_all, world, tolerance, dd2_all, metrics_only)
+ *         adds the world * PCRS_ICP_NSUMS doubles in rank order (identical on every rank), then
+ *         metrics, convergence test, solve and compose on the device (icp.rs:163-186); the
+ *         increment is applied to the shard by the next accumulate.  dd2_all: dist*dist of ALL
+ *         n_source_total points in index order, summed left to right in f32 as icp.rs:277-281
+ *         does; NULL takes the rmse from the f64 sums (then pcrs_icp_shard_rmse_dev sets the
+ *         reported value afterwards).  metrics_only: the single pass of icp.rs:190-197
+ *   pcrs_icp_shard_state(icp, &result, &done, &last_live)   waits for the stream
+ *         done: the loop has ended (iterations queued behind it were no-ops); last_live: the
+ *         1-based iteration the reported metrics come from (0: none)
+ *   pcrs_icp_shard_finish(icp)    applies the last increment to the working copy
+ *
+ * Every rank passes the same arguments and sees the same state, so all ranks take the same
+ * decisions without exchanging them. */
+int pcrs_icp_shard_begin(pcrs_icp *icp, size_t n_source_total);
+int pcrs_icp_shard_accumulate_dev(pcrs_icp *icp, int mode, float max_distance, uint32_t iteration,
+                                  double *dsums, const float **dd2);
+int pcrs_icp_shard_update_dev(pcrs_icp *icp, int mode, const double *dsums_all, uint32_t world,
+                              float tolerance, const float *dd2_all, int metrics_only);
+int pcrs_icp_shard_rmse_dev(pcrs_icp *icp, const float *dd2_all);
+int pcrs_icp_shard_state(pcrs_icp *icp, pcrs_icp_result *out, int *done, uint32_t *last_live);
+int pcrs_icp_shard_finish(pcrs_icp *icp);
+
 /* Whole registration on host buffers (create + run + destroy). */
 int pcrs_icp_register(pcrs_ctx *ctx, int mode, const float *sx, const float *sy, const float *sz, size_t n,
              const float *tx, const float *ty, const float *tz, size_t m, const float *tnx,

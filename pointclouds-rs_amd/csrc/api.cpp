@@ -1222,6 +1222,10 @@ struct pcrs_icp {
     // left-to-right f32 sum over one of them (icp.rs:277-281)
     DevBuf d2seq, seq_work;
     size_t seq_scalars_bytes = 0;
+    // source split over ranks (pcrs_icp_shard_*): points of all shards together, and the work
+    // space of the f32 sum over their gathered dist*dist
+    size_t shard_total = 0;
+    DevBuf shard_seq;
 };
 
 namespace {
@@ -1301,6 +1305,38 @@ int icp_alloc_work(pcrs_icp *icp) {
     icp->seq_scalars_bytes = (pcrs_sor_stats_scalars_bytes() + 63) & ~(size_t)63;
     PCRS_HIP_CHECK(ctx, icp->seq_work.alloc(ctx, icp->seq_scalars_bytes + pcrs_sor_stats_workspace(n)));
     return PCRS_OK;
+}
+
+// Fresh loop state on the device (identity transform, no previous rmse).  *hs: pinned host copy
+// that the read-backs of the loop land in; *hfail: a pinned word behind it.
+int icp_state_init(pcrs_icp *icp, IcpLoopState **hs_out, uint32_t **hfail_out, IcpLoopState **ds_out) {
+    pcrs_ctx *ctx = icp->ctx;
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState) + 64, &pin));
+    IcpLoopState *hs = reinterpret_cast<IcpLoopState *>(pin);
+    uint32_t *hfail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pin) +
+                                                   ((sizeof(IcpLoopState) + 15) & ~(size_t)15));
+    *hfail = 0;
+    std::memset(hs, 0, sizeof(*hs));
+    hs->cum_r[0] = hs->cum_r[4] = hs->cum_r[8] = 1.0f;
+    hs->inc_r[0] = hs->inc_r[4] = hs->inc_r[8] = 1.0f;
+    hs->prev_rmse = hs->last_rmse = std::numeric_limits<float>::infinity();
+    IcpLoopState *ds = icp->state.as<IcpLoopState>();
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, sizeof(*hs), hipMemcpyHostToDevice, ctx->stream));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // hs is reused for the read-backs
+    *hs_out = hs;
+    *hfail_out = hfail;
+    *ds_out = ds;
+    return PCRS_OK;
+}
+
+void result_from_state(const IcpLoopState *hs, pcrs_icp_result *out) {
+    std::memcpy(out->rotation, hs->cum_r, sizeof(hs->cum_r));
+    std::memcpy(out->translation, hs->cum_t, sizeof(hs->cum_t));
+    out->fitness = hs->last_fitness;
+    out->rmse = hs->last_rmse;
+    out->converged = hs->converged ? 1 : 0;
+    out->num_iterations = hs->num_iterations;
 }
 
 }  // namespace
@@ -1564,19 +1600,9 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     PCRS_TRY(pcrs_icp_reset(icp));
     // The loop state lives on the device (icp_tail_step carries icp.rs:147-188), so the host only
     // looks at it every few iterations; iterations queued behind the end of the loop are no-ops.
-    void *pin = nullptr;
-    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState) + 64, &pin));
-    IcpLoopState *hs = reinterpret_cast<IcpLoopState *>(pin);
-    uint32_t *hfail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pin) +
-                                                   ((sizeof(IcpLoopState) + 15) & ~(size_t)15));
-    *hfail = 0;
-    std::memset(hs, 0, sizeof(*hs));
-    hs->cum_r[0] = hs->cum_r[4] = hs->cum_r[8] = 1.0f;
-    hs->inc_r[0] = hs->inc_r[4] = hs->inc_r[8] = 1.0f;
-    hs->prev_rmse = hs->last_rmse = std::numeric_limits<float>::infinity();
-    IcpLoopState *ds = icp->state.as<IcpLoopState>();
-    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, sizeof(*hs), hipMemcpyHostToDevice, ctx->stream));
-    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // hs is reused for the read-backs
+    IcpLoopState *hs = nullptr, *ds = nullptr;
+    uint32_t *hfail = nullptr;
+    PCRS_TRY(icp_state_init(icp, &hs, &hfail, &ds));
     float *cx = icp->cur[0].as<float>(), *cy = icp->cur[1].as<float>(), *cz = icp->cur[2].as<float>();
     // The convergence test |prev_rmse - rmse| < tolerance (icp.rs:173) can only fire for a
     // positive tolerance.  Then every iteration takes its rmse from the reference's own sum
@@ -1640,13 +1666,139 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
         PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::memcpy(out->rotation, hs->cum_r, sizeof(hs->cum_r));
-    std::memcpy(out->translation, hs->cum_t, sizeof(hs->cum_t));
-    out->fitness = hs->last_fitness;
-    out->rmse = hs->last_rmse;
-    out->converged = hs->converged ? 1 : 0;
-    out->num_iterations = hs->num_iterations;
+    result_from_state(hs, out);
     return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
+}
+
+// ---- the loop with the source split over ranks: see the header for the protocol
+
+static int icp_check_mode(pcrs_icp *icp, int mode) {
+    pcrs_ctx *ctx = icp->ctx;
+    if (mode != PCRS_ICP_POINT_TO_POINT && mode != PCRS_ICP_POINT_TO_PLANE)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "unknown ICP mode %d", mode);
+    if (mode == PCRS_ICP_POINT_TO_PLANE && (!icp->tnx || icp->n_normals != icp->m))
+        return pcrs_set_err(ctx, PCRS_ERR_NORMALS_MISMATCH,
+                            "target_normals length (%zu) does not match target cloud length (%zu)",
+                            icp->n_normals, icp->m);
+    return PCRS_OK;
+}
+
+int pcrs_icp_shard_begin(pcrs_icp *icp, size_t n_source_total) try {
+    if (!icp) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (n_source_total < icp->n || n_source_total >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG,
+                            "n_source_total (%zu) must cover this shard (%zu points)",
+                            n_source_total, icp->n);
+    if (icp->m == 0) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "empty target");
+    PCRS_TRY(pcrs_icp_reset(icp));
+    IcpLoopState *hs = nullptr, *ds = nullptr;
+    uint32_t *hfail = nullptr;
+    PCRS_TRY(icp_state_init(icp, &hs, &hfail, &ds));
+    icp->shard_total = n_source_total;
+    PCRS_HIP_CHECK(ctx, icp->shard_seq.alloc(ctx, icp->seq_scalars_bytes +
+                                                      pcrs_sor_stats_workspace(n_source_total)));
+    return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
+}
+
+int pcrs_icp_shard_accumulate_dev(pcrs_icp *icp, int mode, float max_distance, uint32_t iteration,
+                                  double *dsums, const float **dd2) try {
+    if (!icp) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (!dsums) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null sums pointer");
+    if (!icp->shard_total && icp->n) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "pcrs_icp_shard_begin has not run");
+    PCRS_TRY(icp_check_mode(icp, mode));
+    float *d2 = icp->d2seq.as<float>() + (size_t)(iteration & 1u) * icp->n;
+    if (dd2) *dd2 = d2;
+    if (icp->n == 0) {  // a rank without points adds nothing
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(dsums, 0, PCRS_ICP_NSUMS * sizeof(double), ctx->stream));
+        return PCRS_OK;
+    }
+    float *cx = icp->cur[0].as<float>(), *cy = icp->cur[1].as<float>(), *cz = icp->cur[2].as<float>();
+    float *const cur_w[3] = {cx, cy, cz};
+    IcpTail tail;
+    tail.state = icp->state.as<IcpLoopState>();
+    tail.n_source = icp->shard_total;
+    tail.sums_only = true;
+    tail.d2seq = d2;
+    tail.perm = icp->perm.as<uint32_t>();
+    return correspond_and_reduce(ctx, icp->target, mode, cx, cy, cz, icp->n, icp->tnx, icp->tny,
+                                 icp->tnz, max_distance, icp->nn_idx.as<uint32_t>(),
+                                 icp->nn_d2.as<float>(), dsums, nullptr, nullptr, tail,
+                                 icp->perm.p != nullptr, iteration > 0 ? cur_w : nullptr);
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
+}
+
+int pcrs_icp_shard_update_dev(pcrs_icp *icp, int mode, const double *dsums_all, uint32_t world,
+                              float tolerance, const float *dd2_all, int metrics_only) try {
+    if (!icp) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (!dsums_all || world == 0) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "no sums to add");
+    if (!icp->shard_seq.p) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "pcrs_icp_shard_begin has not run");
+    PCRS_TRY(icp_check_mode(icp, mode));
+    IcpTail tail;
+    tail.state = icp->state.as<IcpLoopState>();
+    tail.n_source = icp->shard_total;
+    tail.tolerance = tolerance;
+    tail.metrics_only = metrics_only != 0;
+    tail.exact = dd2_all != nullptr;
+    tail.seq_scalars = icp->shard_seq.p;
+    tail.seq_work = reinterpret_cast<char *>(icp->shard_seq.p) + icp->seq_scalars_bytes;
+    tail.seq_work_bytes = icp->shard_seq.bytes - icp->seq_scalars_bytes;
+    if (tail.exact)
+        PCRS_TRY(pcrs_launch_seq_sum(ctx, dd2_all, icp->shard_total, tail.seq_scalars, tail.seq_work,
+                                     tail.seq_work_bytes));
+    return pcrs_launch_icp_shard_tail(ctx, mode, dsums_all, world, icp->sums.as<double>(), tail);
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
+}
+
+int pcrs_icp_shard_rmse_dev(pcrs_icp *icp, const float *dd2_all) try {
+    if (!icp) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (!dd2_all || !icp->shard_seq.p) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "nothing to sum");
+    void *scalars = icp->shard_seq.p;
+    PCRS_TRY(pcrs_launch_seq_sum(ctx, dd2_all, icp->shard_total, scalars,
+                                 reinterpret_cast<char *>(scalars) + icp->seq_scalars_bytes,
+                                 icp->shard_seq.bytes - icp->seq_scalars_bytes));
+    return pcrs_launch_icp_exact_rmse(ctx, icp->state.as<IcpLoopState>(), scalars);
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
+}
+
+int pcrs_icp_shard_state(pcrs_icp *icp, pcrs_icp_result *out, int *done, uint32_t *last_live) try {
+    if (!icp || !out) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState) + 64, &pin));
+    IcpLoopState *hs = reinterpret_cast<IcpLoopState *>(pin);
+    PCRS_TRY(pcrs_launch_publish(ctx, icp->state.as<IcpLoopState>(), hs, sizeof(*hs)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    result_identity(out);
+    result_from_state(hs, out);
+    if (done) *done = hs->done ? 1 : 0;
+    if (last_live) *last_live = hs->last_live;
+    return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(icp ? icp->ctx : nullptr);
+}
+
+int pcrs_icp_shard_finish(pcrs_icp *icp) try {
+    if (!icp) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = icp->ctx;
+    PCRS_TRY(bind_device(ctx));
+    return pcrs_launch_transform_state(ctx, icp->cur[0].as<float>(), icp->cur[1].as<float>(),
+                                       icp->cur[2].as<float>(), icp->n, icp->state.as<IcpLoopState>());
 } catch (...) {
     return pcrs_on_exception(icp ? icp->ctx : nullptr);
 }

@@ -400,6 +400,27 @@ __global__ void icp_tail_kernel(int mode, const double *sums, float n_source, fl
     icp_tail_step(work, mode, sums, n_source, tolerance, metrics_only != 0, exact_sum, st);
 }
 
+// The same for a source split over ranks: the sums of the shards, gathered from all ranks, are
+// added in rank order first, so that every rank continues from bit-identical totals.
+__global__ __launch_bounds__(64) void icp_shard_tail_kernel(int mode, const double *sums_all,
+                                                            uint32_t world, double *sums,
+                                                            float n_source, float tolerance,
+                                                            int metrics_only, const float *exact_sum,
+                                                            IcpLoopState *st) {
+    __shared__ pcrs_math::Work work;
+    __shared__ double total[PCRS_ICP_NSUMS];
+    if (st->done) return;
+    if (threadIdx.x < PCRS_ICP_NSUMS) {
+        double v = 0.0;
+        for (uint32_t r = 0; r < world; ++r) v += sums_all[(size_t)r * PCRS_ICP_NSUMS + threadIdx.x];
+        total[threadIdx.x] = v;
+        sums[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        icp_tail_step(work, mode, total, n_source, tolerance, metrics_only != 0, exact_sum, st);
+}
+
 // After a loop whose rmse values came from the f64 sums (tolerance <= 0: the convergence test
 // can never fire, so only the reported value matters): the reported rmse from the exact sum.
 __global__ void icp_exact_rmse_kernel(IcpLoopState *st, const float *exact_sum) {
@@ -437,6 +458,19 @@ int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, const Ic
     return PCRS_OK;
 }
 
+int pcrs_launch_icp_shard_tail(pcrs_ctx *ctx, int mode, const double *d_sums_all, uint32_t world,
+                               double *d_sums, const IcpTail &tail) {
+    const float *exact_sum =
+        tail.exact ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(tail.seq_scalars) +
+                                                     pcrs_seq_sum_result_offset())
+                   : nullptr;
+    hipLaunchKernelGGL(pcrs::icp_shard_tail_kernel, dim3(1), dim3(64), 0, ctx->stream, mode,
+                       d_sums_all, world, d_sums, (float)tail.n_source, tail.tolerance,
+                       tail.metrics_only ? 1 : 0, exact_sum, tail.state);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
 int pcrs_launch_icp_exact_rmse(pcrs_ctx *ctx, IcpLoopState *d_state, const void *d_seq_scalars) {
     hipLaunchKernelGGL(pcrs::icp_exact_rmse_kernel, dim3(1), dim3(1), 0, ctx->stream, d_state,
                        reinterpret_cast<const float *>(reinterpret_cast<const char *>(d_seq_scalars) +
@@ -461,12 +495,12 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            uint32_t *tgt_idx_out, float *dist_out, double *d_sums,
                            const IcpTail &tail) {
     IcpLoopState *st = tail.state;
-    if (tail.exact && (!tail.d2seq || !tail.seq_scalars || !tail.seq_work))
+    if (!tail.sums_only && tail.exact && (!tail.d2seq || !tail.seq_scalars || !tail.seq_work))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "exact rmse needs its work buffers");
     if (n == 0) {
         PCRS_HIP_CHECK(ctx,
                        hipMemsetAsync(d_sums, 0, PCRS_ICP_NSUMS * sizeof(double), ctx->stream));
-        if (st) {
+        if (st && !tail.sums_only) {
             IcpTail t2 = tail;
             t2.exact = false;  // no correspondences: the tail never looks at a sum
             return pcrs_launch_icp_tail(ctx, mode, d_sums, t2);
@@ -491,9 +525,9 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
                            tail.d2seq, tail.perm, st);
     hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, partials,
                        (uint32_t)blocks, d_sums, mode, (float)tail.n_source, tail.tolerance,
-                       tail.metrics_only ? 1 : 0, (st && !tail.exact) ? 1 : 0, st);
+                       tail.metrics_only ? 1 : 0, (st && !tail.exact && !tail.sums_only) ? 1 : 0, st);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
-    if (st && tail.exact) {
+    if (st && tail.exact && !tail.sums_only) {
         // the reference's rmse: dist*dist summed left to right in f32, in source order
         PCRS_TRY(pcrs_launch_seq_sum(ctx, tail.d2seq, n, tail.seq_scalars, tail.seq_work,
                                      tail.seq_work_bytes));

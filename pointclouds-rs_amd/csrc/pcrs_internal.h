@@ -320,10 +320,17 @@ struct IcpTail {
     bool exact = false;
     void *seq_scalars = nullptr, *seq_work = nullptr;
     size_t seq_work_bytes = 0;
+    // sums_only: the reduction stops at d_sums (skipped once the loop state says done); the tail
+    // follows later, on the sums of all shards (pcrs_launch_icp_shard_tail)
+    bool sums_only = false;
 };
 // After the sums of an iteration are in d_sums: metrics, convergence test, solve, compose
 // (pcrs_launch_icp_reduce does the same inside its last kernel when given a loop state).
 int pcrs_launch_icp_tail(pcrs_ctx *ctx, int mode, const double *d_sums, const IcpTail &tail);
+// The tail over the sums of `world` shards (world * PCRS_ICP_NSUMS doubles, added in rank order
+// into d_sums first).
+int pcrs_launch_icp_shard_tail(pcrs_ctx *ctx, int mode, const double *d_sums_all, uint32_t world,
+                               double *d_sums, const IcpTail &tail);
 // last_rmse of the state from the exact sum left by pcrs_launch_seq_sum in d_seq_scalars
 int pcrs_launch_icp_exact_rmse(pcrs_ctx *ctx, IcpLoopState *d_state, const void *d_seq_scalars);
 // cur = inc(cur) with the increment read from the device state; no-op once the loop is done.

@@ -104,6 +104,12 @@ SIGNATURES = {
     "pcrs_icp_apply": (C.c_int, [_V, c_float_p, c_float_p]),
     "pcrs_icp_get_current": (C.c_int, [_V, _V, _V, _V]),
     "pcrs_icp_run": (C.c_int, [_V, C.c_int, C.c_uint32, C.c_float, C.c_float, C.POINTER(IcpResultC)]),
+    "pcrs_icp_shard_begin": (C.c_int, [_V, C.c_size_t]),
+    "pcrs_icp_shard_accumulate_dev": (C.c_int, [_V, C.c_int, C.c_float, C.c_uint32, _V, C.POINTER(_V)]),
+    "pcrs_icp_shard_update_dev": (C.c_int, [_V, C.c_int, _V, C.c_uint32, C.c_float, _V, C.c_int]),
+    "pcrs_icp_shard_rmse_dev": (C.c_int, [_V, _V]),
+    "pcrs_icp_shard_state": (C.c_int, [_V, C.POINTER(IcpResultC), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
+    "pcrs_icp_shard_finish": (C.c_int, [_V]),
     "pcrs_icp_register": (C.c_int, [_V, C.c_int] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t, C.c_uint32, C.c_float, C.c_float, C.POINTER(IcpResultC)]),
     "pcrs_index_last_stats": (C.c_int, [_V, C.POINTER(C.c_uint64)]),
     "pcrs_ctx_timing": (C.c_int, [_V, C.c_int]),

@@ -195,6 +195,48 @@ class HipEngine:
                                              C.byref(res)))
         return res
 
+    # -- ICP with the source split over ranks: both halves of an iteration are only queued
+    def icp_shard_begin(self, h, n_source_total):
+        self.ctx.check(self.lib.pcrs_icp_shard_begin(h, n_source_total))
+
+    def icp_shard_accumulate(self, h, mode, max_d, iteration, sums, n_local):
+        """Queues search + reduction of this shard into the device tensor `sums`; returns the
+        shard's dist*dist of this iteration (input order) as a tensor over the handle's memory."""
+        p = _V()
+        self.ctx.check(self.lib.pcrs_icp_shard_accumulate_dev(h, mode, float(max_d), iteration,
+                                                              self._p(sums), C.byref(p)))
+        return self._view_f32(p.value, n_local)
+
+    def _view_f32(self, address, n):
+        """Tensor over n floats of device memory the library owns (no copy)."""
+        if not n:
+            return self.empty(0)
+
+        class _Mem:  # what torch.as_tensor reads from an object that exposes device memory
+            __cuda_array_interface__ = dict(shape=(n,), typestr="<f4", data=(address, False),
+                                            version=2)
+
+        return self.torch.as_tensor(_Mem(), device=self.device)
+
+    def icp_shard_update(self, h, mode, sums_all, world, tolerance, d2_all, metrics_only=False):
+        self.ctx.check(self.lib.pcrs_icp_shard_update_dev(
+            h, mode, self._p(sums_all), world, float(tolerance),
+            self._p(d2_all) if d2_all is not None else _V(None), 1 if metrics_only else 0))
+
+    def icp_shard_rmse(self, h, d2_all):
+        self.ctx.check(self.lib.pcrs_icp_shard_rmse_dev(h, self._p(d2_all)))
+
+    def icp_shard_state(self, h):
+        """(result, done, last_live) — waits for everything queued so far."""
+        res = _ffi.IcpResultC()
+        done = C.c_int()
+        live = C.c_uint32()
+        self.ctx.check(self.lib.pcrs_icp_shard_state(h, C.byref(res), C.byref(done), C.byref(live)))
+        return res, bool(done.value), int(live.value)
+
+    def icp_shard_finish(self, h):
+        self.ctx.check(self.lib.pcrs_icp_shard_finish(h))
+
     def compose(self, ra, ta, rb, tb):
         ro = (C.c_float * 9)()
         to = (C.c_float * 3)()
@@ -343,10 +385,23 @@ def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
 
 
 def icp_sharded(engine, coll, mode, src_shard, n_src_total, tgt, tgt_normals, max_iterations=50,
-                tolerance=1e-5, max_correspondence_distance=math.inf):
-    """ICP with the source sharded over ranks and the target replicated
-    (loop of crates/registration/src/icp.rs:125-206 / icp_plane.rs:20-97)."""
+                tolerance=1e-5, max_correspondence_distance=math.inf, batch=4):
+    """ICP with the source sharded over ranks (contiguous index ranges, rank order = index order)
+    and the target replicated (loop of crates/registration/src/icp.rs:125-206 /
+    icp_plane.rs:20-97).
+
+    The loop state lives on every rank's device.  Per iteration a rank queues the search and
+    reduction of its shard, the ranks all-gather their PCRS_ICP_NSUMS partial sums (device
+    collective), and every rank queues the same tail (add in rank order, metrics, convergence
+    test, solve, compose): identical inputs, identical kernels, so all ranks hold the same state
+    and take the same decisions.  The host looks at the state once per `batch` iterations;
+    iterations queued behind the end of the loop are no-ops.  With a positive tolerance the rmse
+    that steers the loop is the reference's own (icp.rs:277-281: dist*dist of all points in index
+    order, summed left to right in f32), so the shards' dist*dist are gathered too (4 B/point per
+    iteration); otherwise only the reported rmse is, once, after the loop.
+    """
     torch = engine.torch
+    world = coll.world
     ident_r = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
     ident_t = (C.c_float * 3)(0, 0, 0)
     out = dict(rotation=ident_r, translation=ident_t, fitness=0.0, rmse=0.0, converged=False,
@@ -354,40 +409,44 @@ def icp_sharded(engine, coll, mode, src_shard, n_src_total, tgt, tgt_normals, ma
     if n_src_total == 0 or tgt[0].numel() == 0:
         out["converged"] = n_src_total == 0 and tgt[0].numel() == 0
         return out
+    counts = [shard_range(n_src_total, world, r)[1] - shard_range(n_src_total, world, r)[0]
+              for r in range(world)]
+    n_local = src_shard[0].numel()
+    assert n_local == counts[coll.rank], "shard length does not match its index range"
+    exact = tolerance > 0
     h = engine.icp_create(src_shard, tgt, tgt_normals)
     try:
-        engine.icp_reset(h)
-        cum_r, cum_t = ident_r, ident_t
-        prev_rmse, last_rmse, last_fit = math.inf, math.inf, 0.0
-        converged, num_it = False, 0
+        engine.icp_shard_begin(h, n_src_total)
+        sums = engine.empty(_ffi.ICP_NSUMS, "float64")
+        d2_of = {}  # iteration -> this shard's dist*dist (two alternating buffers of the handle)
 
-        def metrics(s):
-            rmse = float(np.float32(math.sqrt(s[1] / s[0])))
-            fit = float(np.float32(np.float32(int(s[0])) / np.float32(n_src_total)))
-            return rmse, fit
+        def iteration(it, metrics_only=False):
+            d2_of[it & 1] = engine.icp_shard_accumulate(h, mode, max_correspondence_distance, it,
+                                                        sums, n_local)
+            sums_all = coll.all_gather_var(torch, sums, [_ffi.ICP_NSUMS] * world)
+            d2_all = coll.all_gather_var(torch, d2_of[it & 1], counts) if exact or metrics_only \
+                else None
+            engine.icp_shard_update(h, mode, sums_all, world, tolerance, d2_all, metrics_only)
 
-        for it in range(max_iterations):
-            num_it = it + 1
-            s = engine.icp_accumulate(h, mode, max_correspondence_distance)
-            s = coll.all_reduce_sum_f64(torch, s, engine.device)
-            if not s[0] > 0:
-                break
-            rmse, fit = metrics(s)
-            last_rmse, last_fit = rmse, fit
-            if abs(np.float32(prev_rmse) - np.float32(rmse)) < np.float32(tolerance):
-                converged = True
-                break
-            prev_rmse = rmse
-            inc_r, inc_t = engine.icp_solve(mode, s)
-            cum_r, cum_t = engine.compose(cum_r, cum_t, inc_r, inc_t)
-            engine.icp_apply(h, inc_r, inc_t)
-        if num_it == 0:
-            s = coll.all_reduce_sum_f64(torch, engine.icp_accumulate(h, mode, max_correspondence_distance),
-                                        engine.device)
-            if s[0] > 0:
-                last_rmse, last_fit = metrics(s)
-        out.update(rotation=cum_r, translation=cum_t, fitness=last_fit, rmse=last_rmse,
-                   converged=converged, num_iterations=num_it)
+        if max_iterations == 0:  # icp.rs:190-197: one metrics pass, identity transform
+            iteration(0, metrics_only=True)
+        it = 0
+        res, done, last_live = None, False, 0
+        while it < max_iterations and not done:
+            nb = min(batch, max_iterations - it)
+            for j in range(nb):
+                iteration(it + j)
+            it += nb
+            res, done, last_live = engine.icp_shard_state(h)
+        engine.icp_shard_finish(h)
+        if max_iterations > 0 and not exact and last_live:
+            # the reported rmse from the reference's sum over the last live iteration
+            d2_all = coll.all_gather_var(torch, d2_of[(last_live - 1) & 1], counts)
+            engine.icp_shard_rmse(h, d2_all)
+        res, done, last_live = engine.icp_shard_state(h)
+        out.update(rotation=res.rotation, translation=res.translation, fitness=float(res.fitness),
+                   rmse=float(res.rmse), converged=bool(res.converged),
+                   num_iterations=int(res.num_iterations))
         return out
     finally:
         engine.icp_destroy(h)

@@ -123,6 +123,92 @@ class CpuEngine:
     def icp_apply(self, h, rot, t):
         h["cur"] = list(self.o.apply_transform(*h["cur"], np.array(rot, np.float32).reshape(3, 3), list(t)))
 
+    # ---- ICP with the source split over ranks: the device-resident loop state of the HIP engine
+    # as a dict, the two halves of an iteration as the library documents them
+    def _sums(self, h, mode, max_d):
+        st = self.o.icp_step(h["cur"], h["tgt"], h["tn"], max_d, algo=1)
+        s = np.zeros(_ffi.ICP_NSUMS)
+        s[0], s[1] = st["n_corr"], st["sum_d2"]
+        if mode == _ffi.ICP_POINT_TO_PLANE:
+            ata = st["plane"][:36].reshape(6, 6)
+            s[2:23] = [ata[r, c] for r in range(6) for c in range(r, 6)]
+            s[23:29] = st["plane"][36:]
+        else:
+            s[2:17] = st["point"]
+        valid = st["tgt_idx"] != 0xFFFFFFFF
+        d2 = np.where(valid, st["dist"] * st["dist"], np.float32(0)).astype(np.float32)
+        return s, d2
+
+    def icp_shard_begin(self, h, n_source_total):
+        self.icp_reset(h)
+        eye = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+        h["st"] = dict(total=n_source_total, done=False, converged=False, it=0, cum_r=eye,
+                       cum_t=(C.c_float * 3)(), inc=None, prev=np.float32(np.inf),
+                       rmse=np.float32(np.inf), fit=np.float32(0), ncorr=np.float32(0), live=0)
+        h["d2"] = {}
+
+    def icp_shard_accumulate(self, h, mode, max_d, iteration, sums, n_local):
+        st = h["st"]
+        if not st["done"]:
+            if iteration > 0 and st["inc"] is not None:
+                self.icp_apply(h, *st["inc"])
+                st["inc"] = None
+            s, d2 = self._sums(h, mode, max_d)
+            sums.copy_(torch.from_numpy(s))
+            h["d2"][iteration & 1] = torch.from_numpy(d2)
+        return h["d2"][iteration & 1]
+
+    def icp_shard_update(self, h, mode, sums_all, world, tolerance, d2_all, metrics_only=False):
+        st = h["st"]
+        if st["done"]:
+            return
+        s = np.zeros(_ffi.ICP_NSUMS)
+        for r in range(world):  # rank order
+            s = s + sums_all.numpy()[r * _ffi.ICP_NSUMS:(r + 1) * _ffi.ICP_NSUMS]
+        if not metrics_only:
+            st["it"] += 1
+        if not s[0] > 0:
+            st["done"] = True
+            return
+        ncorr = np.float32(int(s[0]))
+        if d2_all is not None:
+            total = np.cumsum(d2_all.numpy(), dtype=np.float32)[-1]  # left to right in f32
+            rmse = np.sqrt(np.float32(total / ncorr))
+        else:
+            rmse = np.float32(np.sqrt(s[1] / s[0]))
+        st.update(rmse=rmse, fit=np.float32(ncorr / np.float32(st["total"])), ncorr=ncorr,
+                  live=1 if metrics_only else st["it"])
+        if metrics_only:
+            st["done"] = True
+            return
+        if abs(np.float32(st["prev"] - rmse)) < np.float32(tolerance):
+            st["converged"] = st["done"] = True
+            return
+        st["prev"] = rmse
+        st["inc"] = self.icp_solve(mode, s)
+        st["cum_r"], st["cum_t"] = self.compose(st["cum_r"], st["cum_t"], *st["inc"])
+
+    def icp_shard_rmse(self, h, d2_all):
+        st = h["st"]
+        if st["live"]:
+            total = np.cumsum(d2_all.numpy(), dtype=np.float32)[-1]
+            st["rmse"] = np.sqrt(np.float32(total / st["ncorr"]))
+
+    def icp_shard_state(self, h):
+        st = h["st"]
+        res = _ffi.IcpResultC()
+        res.rotation[:] = list(st["cum_r"])
+        res.translation[:] = list(st["cum_t"])
+        res.fitness, res.rmse = float(st["fit"]), float(st["rmse"])
+        res.converged, res.num_iterations = int(st["converged"]), st["it"]
+        return res, st["done"], st["live"]
+
+    def icp_shard_finish(self, h):
+        st = h["st"]
+        if not st["done"] and st["inc"] is not None:
+            self.icp_apply(h, *st["inc"])
+            st["inc"] = None
+
     def compose(self, ra, ta, rb, tb):
         ro, to = (C.c_float * 9)(), (C.c_float * 3)()
         self.lib.pcrs_compose(ra, ta, rb, tb, ro, to)

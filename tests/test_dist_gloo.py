@@ -62,6 +62,13 @@ def _worker(rank, world, port, n_total, q):
                     12, 0.0)
     out["icp"] = dict(rot=list(r["rotation"]), t=list(r["translation"]), rmse=r["rmse"],
                       fitness=r["fitness"], iters=r["num_iterations"])
+    # the same with a live tolerance: the loop must end in the reference's iteration
+    r = icp_sharded(eng, coll, _ffi.ICP_POINT_TO_PLANE, [eng.from_numpy(c[sb:se]) for c in src],
+                    len(src[0]), [eng.from_numpy(c) for c in tgt], [eng.from_numpy(c) for c in tn],
+                    30, 1e-4)
+    out["icp_tol"] = dict(rot=list(r["rotation"]), t=list(r["translation"]), rmse=r["rmse"],
+                          fitness=r["fitness"], iters=r["num_iterations"],
+                          converged=r["converged"])
     q.put(out)
     dist.destroy_process_group()
 
@@ -117,3 +124,13 @@ def test_sharded_matches_single_process(oracle):
         assert abs(o["icp"]["rmse"] - ref.rmse) <= 1e-4 * ref.rmse + 1e-6
         assert np.allclose(o["icp"]["rot"], list(ref.rot), atol=2e-5)
         assert np.allclose(o["icp"]["t"], list(ref.t), atol=5e-5)
+    rc, ref, _ = oracle.icp(1, src, tgt, tn, max_iter=30, tol=1e-4, algo=1)
+    assert 1 < ref.num_iterations < 30 and ref.converged
+    assert outs[0]["icp_tol"] == outs[1]["icp_tol"]  # bit for bit the same on both ranks
+    for o in outs:
+        assert o["icp_tol"]["iters"] == ref.num_iterations
+        assert o["icp_tol"]["converged"] == bool(ref.converged)
+        assert o["icp_tol"]["fitness"] == ref.fitness
+        assert abs(o["icp_tol"]["rmse"] - ref.rmse) <= 1e-4 * ref.rmse + 1e-6
+        assert np.allclose(o["icp_tol"]["rot"], list(ref.rot), atol=2e-5)
+        assert np.allclose(o["icp_tol"]["t"], list(ref.t), atol=5e-5)

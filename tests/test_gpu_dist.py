@@ -30,18 +30,7 @@ def _cloud():
     return synth.kitti_scene(3, 51001, 2000, 1000)  # 58001 points: uneven shards
 
 
-def _target_normals(eng, tgt):
-    """Normals of the ICP target from the library itself (k = 12), as NumPy columns."""
-    cols = [eng.from_numpy(c) for c in tgt]
-    n = len(tgt[0])
-    out = [eng.empty(n) for _ in range(3)]
-    ix = eng.build_index(*cols, 12)
-    eng.sor_normals_range(ix, 0, n, 0, 12, (0.0, 0.0, 0.0), None, *out)
-    eng.destroy_index(ix)
-    return [t.cpu().numpy() for t in out]
-
-
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, icp_inputs):
     for p in (os.path.join(ROOT, "pointclouds-rs_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -71,29 +60,50 @@ def _worker(rank, world, port, q):
     from pointclouds_rs import _ffi, synth
     from pointclouds_rs.dist import icp_sharded
 
-    tgt = synth.hemisphere(4000, 99, 5.0)
-    tn = _target_normals(eng, tgt)
-    P = np.stack(tgt, 1)
-    S = (P @ synth.rot_z(0.04).T + np.array([0.2, -0.1, 0.05], dtype=F)).astype(F)
+    # the parent made the inputs with the oracle and checks against the oracle's run on them
+    inp = np.load(icp_inputs)
+    tgt = [inp["t%d" % a] for a in range(3)]
+    tn = [inp["n%d" % a] for a in range(3)]
+    S = np.stack([inp["s%d" % a] for a in range(3)], 1)
     sb, se = shard_range(len(S), world, rank)
     r = icp_sharded(eng, coll, _ffi.ICP_POINT_TO_PLANE,
                     [eng.from_numpy(np.ascontiguousarray(S[sb:se, a])) for a in range(3)], len(S),
                     [eng.from_numpy(c) for c in tgt], [eng.from_numpy(c) for c in tn], 12, 0.0)
     out["icp"] = dict(rot=list(r["rotation"]), t=list(r["translation"]), rmse=r["rmse"],
                       fitness=r["fitness"], iters=r["num_iterations"])
+    # the same with a live tolerance: the loop must end in the reference's iteration
+    r = icp_sharded(eng, coll, _ffi.ICP_POINT_TO_PLANE,
+                    [eng.from_numpy(np.ascontiguousarray(S[sb:se, a])) for a in range(3)], len(S),
+                    [eng.from_numpy(c) for c in tgt], [eng.from_numpy(c) for c in tn], 30, 1e-4)
+    out["icp_tol"] = dict(rot=list(r["rotation"]), t=list(r["translation"]), rmse=r["rmse"],
+                          fitness=r["fitness"], iters=r["num_iterations"],
+                          converged=r["converged"])
     q.put(out)
     dist.destroy_process_group()
 
 
+def _icp_inputs(oracle):
+    from pointclouds_rs import synth
+
+    tgt = synth.hemisphere(4000, 99, 5.0)
+    tn = oracle.normals(*tgt, 12, algo=1)
+    src = oracle.apply_transform(*tgt, synth.rot_z(0.04), (0.2, -0.1, 0.05))
+    return src, tgt, tn
+
+
 @pytest.mark.timeout(300)
-def test_two_ranks_both_ownerships(oracle):
+def test_two_ranks_both_ownerships(oracle, tmp_path):
     import queue
 
     world = 2
+    src, tgt, tn = _icp_inputs(oracle)
+    icp_inputs = str(tmp_path / "icp_inputs.npz")
+    np.savez(icp_inputs, **{"s%d" % a: src[a] for a in range(3)},
+             **{"t%d" % a: tgt[a] for a in range(3)}, **{"n%d" % a: tn[a] for a in range(3)})
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, icp_inputs)) for r in range(world)]
     for p in procs:
         p.start()
     outs = []
@@ -131,16 +141,21 @@ def test_two_ranks_both_ownerships(oracle):
                 assert np.abs(got.astype(np.float64) - ref[pt]).max() <= 1e-5
         assert np.array_equal(np.sort(np.concatenate(pts)), np.arange(n_total))
     # ICP: both ranks hold the same transform, equal to the oracle's single-process run
-    from pointclouds_rs import synth
-
-    tgt = synth.hemisphere(4000, 99, 5.0)
-    tn = oracle.normals(*tgt, 12, algo=1)
-    src = oracle.apply_transform(*tgt, synth.rot_z(0.04), (0.2, -0.1, 0.05))
     rc, ref, _ = oracle.icp(1, src, tgt, tn, max_iter=12, tol=0.0, algo=1)
     assert outs[0]["icp"]["rot"] == outs[1]["icp"]["rot"] and outs[0]["icp"]["t"] == outs[1]["icp"]["t"]
     for o in outs:
         assert o["icp"]["iters"] == ref.num_iterations == 12
         assert o["icp"]["fitness"] == ref.fitness
-        assert abs(o["icp"]["rmse"] - ref.rmse) <= 1e-4 * ref.rmse + 1e-6
-        assert np.allclose(o["icp"]["rot"], list(ref.rot), atol=2e-5)
-        assert np.allclose(o["icp"]["t"], list(ref.t), atol=5e-5)
+        assert o["icp"]["rmse"] == ref.rmse
+        assert np.allclose(o["icp"]["rot"], list(ref.rot), rtol=0, atol=2.5e-7)
+        assert np.allclose(o["icp"]["t"], list(ref.t), rtol=0, atol=2.5e-7)
+    rc, ref, _ = oracle.icp(1, src, tgt, tn, max_iter=30, tol=1e-4, algo=1)
+    assert 1 < ref.num_iterations < 30 and ref.converged
+    assert outs[0]["icp_tol"] == outs[1]["icp_tol"]  # bit for bit the same on both ranks
+    for o in outs:
+        assert o["icp_tol"]["iters"] == ref.num_iterations
+        assert o["icp_tol"]["converged"] == bool(ref.converged)
+        assert o["icp_tol"]["fitness"] == ref.fitness
+        assert o["icp_tol"]["rmse"] == ref.rmse  # the reference's own f32 sum, gathered over the ranks
+        assert np.allclose(o["icp_tol"]["rot"], list(ref.rot), rtol=0, atol=2.5e-7)
+        assert np.allclose(o["icp_tol"]["t"], list(ref.t), rtol=0, atol=2.5e-7)

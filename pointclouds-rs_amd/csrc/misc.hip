@@ -181,13 +181,27 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_partial_kernel(
         }
     }
 
+    // Lane totals -> block totals through LDS: the lanes of a wave lay their NS sums down as one
+    // row each, then two lanes per sum add 32 rows apiece, top to bottom (174 f64 shuffles per
+    // wave cost 6 us of this kernel's 14).  The order is fixed: even lanes, odd lanes, their sum,
+    // then the waves in order.
+    constexpr int ROW = NS | 1;  // an odd count of doubles per row spreads the rows over the banks
+    __shared__ double rows[ICP_THREADS][ROW];
     __shared__ double wsum[ICP_THREADS / 64][NS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        double v = acc[i];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) wsum[wave][i] = v;
+    for (int i = 0; i < NS; ++i) rows[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    {
+        const int col = lane >> 1, half = lane & 1;
+        double v = 0.0;
+        if (col < NS) {
+            const double(*r)[ROW] = rows + wave * 64 + half;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) v += r[2 * j][col];
+        }
+        v += __shfl_down(v, 1, 64);  // even rows + odd rows
+        if (col < NS && half == 0) wsum[wave][col] = v;
     }
     __syncthreads();
     if (threadIdx.x < PCRS_ICP_NSUMS) {

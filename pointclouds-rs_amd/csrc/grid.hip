@@ -287,7 +287,9 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_scatter_kernel(const float 
 __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp, SortPlan sp,
                                                                const uint32_t *table,
                                                                uint32_t *cell_start, float4 *spts,
-                                                               uint32_t *nonempty) {
+                                                               float *spts3, uint32_t *nonempty) {
+    // spts3 (nullable): the same points without their index, 12 bytes apart (what the
+    // lane-per-query search kernel reads)
     __shared__ uint32_t cnt[1u << FINE_MAX_SHIFT];
     __shared__ uint32_t wsum[GB_THREADS / 64];
     const uint32_t b = blockIdx.x;
@@ -375,17 +377,30 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
         }
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < end - begin; t += GB_THREADS) spts[begin + t] = stage[t];
+        if (spts3) {
+            const float *sf = reinterpret_cast<const float *>(stage);
+            float *o3 = spts3 + (size_t)begin * 3;
+            for (uint32_t t = threadIdx.x; t < 3u * (end - begin); t += GB_THREADS)
+                o3[t] = sf[(t / 3u) * 4u + t % 3u];
+        }
         return;
     }
+    auto put = [&](uint32_t at, const float4 &p) {
+        spts[at] = p;
+        if (spts3) {
+            spts3[(size_t)at * 3] = p.x;
+            spts3[(size_t)at * 3 + 1] = p.y;
+            spts3[(size_t)at * 3 + 2] = p.z;
+        }
+    };
 #pragma unroll
     for (int h = 0; h < FINE_HELD; ++h) {
         const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
-        if (i < end) spts[atomicAdd(&cnt[held_cell[h]], 1u)] = held[h];
+        if (i < end) put(atomicAdd(&cnt[held_cell[h]], 1u), held[h]);
     }
     for (uint32_t i = begin + threadIdx.x + FINE_HELD * GB_THREADS; i < end; i += GB_THREADS) {
         const float4 p = tmp[i];
-        const uint32_t at = atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u);
-        spts[at] = p;
+        put(atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u), p);
     }
 }
 
@@ -1455,7 +1470,7 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
 static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                               uint32_t m, const SortPlan &sp, uint32_t *table, uint32_t *table_sums,
                               float4 *tmp, float4 *sorted, uint32_t *cell_start,
-                              uint32_t *d_nonempty) {
+                              uint32_t *d_nonempty, float *sorted3 = nullptr) {
     const size_t entries = (size_t)sp.nb * sp.nblk;
     hipLaunchKernelGGL(coarse_hist_kernel, dim3(sp.nblk), dim3(GB_THREADS), sp.nb * sizeof(uint32_t),
                        ctx->stream, x, y, z, m, sp, table);
@@ -1469,7 +1484,7 @@ static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, con
     hipLaunchKernelGGL(coarse_scatter_kernel, dim3(sp.nblk), dim3(GB_THREADS),
                        sp.nb * sizeof(uint32_t), ctx->stream, x, y, z, m, sp, table, tmp);
     hipLaunchKernelGGL(fine_sort_kernel, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp, sp,
-                       table, cell_start, sorted, d_nonempty);
+                       table, cell_start, sorted, sorted3, d_nonempty);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
@@ -1527,7 +1542,10 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     const double max_cells = cells_per_point * (double)nvalid + 4096.0;
     GridGeom g{};
     uint32_t ncell = 0;
-    DevBuf counts, cell_id, table, table_sums, tmp, sorted;
+    DevBuf counts, cell_id, table, table_sums, tmp, sorted, sorted3;
+    // searches for more than one neighbour read an index-free copy of the sorted points: the
+    // sort leaves it too (a 1-NN index never needs it)
+    const bool want3 = k_hint > 1;
     // sized for the largest grid the budget allows: no reallocation between attempts
     PCRS_HIP_CHECK(ctx, counts.alloc(ctx, ((size_t)max_cells + 8) * sizeof(uint32_t)));
     uint32_t *h_nonempty = reinterpret_cast<uint32_t *>(pin);
@@ -1550,11 +1568,13 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             if (!tmp.p) {
                 PCRS_HIP_CHECK(ctx, tmp.alloc(ctx, nvalid * sizeof(float4)));
                 PCRS_HIP_CHECK(ctx, sorted.alloc(ctx, nvalid * sizeof(float4)));
+                if (want3) PCRS_HIP_CHECK(ctx, sorted3.alloc(ctx, nvalid * 3 * sizeof(float)));
             }
             PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_nonempty, 0, sizeof(uint32_t), ctx->stream));
             PCRS_TRY(run_two_level_sort(ctx, ix->x, ix->y, ix->z, m, sp, table.as<uint32_t>(),
                                         table_sums.as<uint32_t>(), tmp.as<float4>(),
-                                        sorted.as<float4>(), counts.as<uint32_t>(), d_nonempty));
+                                        sorted.as<float4>(), counts.as<uint32_t>(), d_nonempty,
+                                        sorted3.as<float>()));
         } else {
             if (!cell_id.p) PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
             PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
@@ -1593,7 +1613,15 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         sorted.p = nullptr;
         sorted.bytes = 0;
         sorted.owner = nullptr;
+        ix->spts3.release();
+        ix->spts3.p = sorted3.p;
+        ix->spts3.bytes = sorted3.bytes;
+        ix->spts3.owner = sorted3.owner;
+        sorted3.p = nullptr;
+        sorted3.bytes = 0;
+        sorted3.owner = nullptr;
     } else {
+        ix->spts3.release();  // made by the first search that wants it (pcrs_launch_knn_grid)
         // scan the histogram into slot ranges and scatter the points.  All buffers come from the
         // context's pool, so the temporaries are released without waiting for the stream.
         DevBuf scan_sums, fill;
@@ -1624,7 +1652,6 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     ix->g = g;
     ix->ncell = ncell;
     ix->algo = PCRS_ALGO_GRID;
-    ix->spts3.release();  // made by the first search that wants it (pcrs_launch_knn_grid)
     return PCRS_OK;
 }
 

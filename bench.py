@@ -37,9 +37,11 @@ K_NRM = 16
 STD_MUL = 1.0
 BYTES_PER_POINT = 29  # 12 B xyz read + 4 B mean + 1 B mask + 12 B normal written
 HBM_PEAK_GBPS = 8000.0
-# f32 vector peak of the chip, unpacked: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x 2 (dual issue
-# is not assumed) = 157 TFLOP/s as FMA = 78.6 T lane-operations per second
+# f32 vector peak of the chip: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-operations
+# per second for ordinary instructions; packed f32 (v_pk_*: two per lane) doubles it to 78.6 T,
+# which as FMA is the 157 TFLOP/s of the data sheet
 VALU_PEAK_TOPS = 78.6
+N_XCD, N_SIMD = 8, 1024  # MI355X: 8 XCDs, 256 CUs x 4 SIMDs
 METRIC = "Mpoints/sec through SOR k=16 + normals on 1M-pt cloud; ICP iters/sec"
 PROFILE_TAG = "r02"
 
@@ -283,8 +285,8 @@ def run_sor_normals(args):
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_launches": launches,
                 "algorithmic_bytes_per_launch": BYTES_PER_POINT * nq,
-                "note": "nominally HBM-bound (29 B/pt), in fact bound by vector-ALU issue and the latency of "
-                        "per-lane candidate loads: see `valu`",
+                "note": "nominally HBM-bound (29 B/pt), in fact bound by vector-ALU issue: the SIMDs are "
+                        "occupied for `valu.issue_busy` of the launch by unpacked f32 instructions",
             },
         }
         prof = profile_counters(avg_kernel_s)
@@ -343,6 +345,16 @@ def profile_counters(avg_kernel_s):
                      "profile": os.path.basename(path), "profile_commit": meta.get("commit")}
                 if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
                     v["wave_wait_frac"] = c["SQ_WAIT_ANY"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"]
+                if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+                    # How long the vector ALUs were occupied.  SQ_ACTIVE_INST_VALU counts
+                    # quad-cycles (an unpacked f32 instruction holds its SIMD for one), summed over
+                    # the 1024 SIMDs; GRBM_GUI_ACTIVE counts the launch's cycles once per XCD.  `peak`
+                    # above is the packed-f32 rate (two lane-ops per lane and quad-cycle): a kernel
+                    # of unpacked instructions, like this one's v_med3_f32 chain, tops out at half.
+                    quads = c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / N_XCD / 4.0
+                    v["issue_busy"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / (N_SIMD * quads)
+                    v["peak_unpacked"] = VALU_PEAK_TOPS / 2.0
+                    v["frac_unpacked"] = v["achieved_Tops"] / (VALU_PEAK_TOPS / 2.0)
                 out["valu"] = v
             return out
     return out

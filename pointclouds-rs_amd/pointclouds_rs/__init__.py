@@ -58,14 +58,21 @@ class PointCloud:
         self._y = np.empty(0, dtype=np.float32)
         self._z = np.empty(0, dtype=np.float32)
         self._normals = None  # (nx, ny, nz) or None, as PointCloud.normals: Option<Normals>
+        # (r, g, b) uint8 columns and an f32 column, or None (cloud.rs:8-10: Option<Colors>,
+        # Option<Vec<f32>>).  Nothing of the PyO3 surface sets them (only file readers do); they
+        # are here so that whatever selects points carries them as cloud.rs:103-140 does.
+        self._colors = None
+        self._intensity = None
 
     @classmethod
-    def _from_columns(cls, x, y, z, normals=None):
+    def _from_columns(cls, x, y, z, normals=None, colors=None, intensity=None):
         pc = cls()
         pc._x = np.ascontiguousarray(x, dtype=np.float32)
         pc._y = np.ascontiguousarray(y, dtype=np.float32)
         pc._z = np.ascontiguousarray(z, dtype=np.float32)
         pc._normals = normals
+        pc._colors = colors
+        pc._intensity = intensity
         return pc
 
     @staticmethod
@@ -102,12 +109,17 @@ class PointCloud:
         return idx
 
     def select(self, indices):
-        # crates/core/src/cloud.rs:103-140 (normals travel with the points)
+        # crates/core/src/cloud.rs:103-140 (normals, colors and intensity travel with the points)
         idx = self._check_indices(indices)
-        normals = None
+        normals = colors = intensity = None
         if self._normals is not None:
             normals = tuple(c[idx] for c in self._normals)
-        return PointCloud._from_columns(self._x[idx], self._y[idx], self._z[idx], normals)
+        if self._colors is not None:
+            colors = tuple(c[idx] for c in self._colors)
+        if self._intensity is not None:
+            intensity = self._intensity[idx]
+        return PointCloud._from_columns(self._x[idx], self._y[idx], self._z[idx], normals, colors,
+                                        intensity)
 
     def select_inverse(self, indices):
         # crates/core/src/cloud.rs:152-162
@@ -315,7 +327,10 @@ def estimate_normals(cloud, k):
     if k < 0:
         raise OverflowError("can't convert negative int to unsigned")
     nx, ny, nz = hip.normals(cloud._x, cloud._y, cloud._z, int(k), (0.0, 0.0, 0.0))
-    return PointCloud._from_columns(cloud._x.copy(), cloud._y.copy(), cloud._z.copy(), (nx, ny, nz))
+    return PointCloud._from_columns(
+        cloud._x.copy(), cloud._y.copy(), cloud._z.copy(), (nx, ny, nz),
+        None if cloud._colors is None else tuple(c.copy() for c in cloud._colors),
+        None if cloud._intensity is None else cloud._intensity.copy())
 
 
 def _icp(mode, source, target, normals, max_iterations, tolerance, max_correspondence_distance):

@@ -33,6 +33,25 @@ def test_select_and_inverse():
         c.select_inverse([7])
 
 
+def test_select_carries_every_attribute():
+    # crates/core/src/cloud.rs:103-140: normals, colors and intensity follow the selected points
+    a = np.arange(18, dtype=np.float32).reshape(6, 3)
+    c = pc.PointCloud.from_numpy(a)
+    c._normals = tuple(np.arange(6, dtype=np.float32) + 10 * k for k in range(3))
+    c._colors = tuple((np.arange(6) + 40 * k).astype(np.uint8) for k in range(3))
+    c._intensity = np.linspace(0.0, 1.0, 6, dtype=np.float32)
+    s = c.select([4, 0, 4])
+    assert np.array_equal(s.to_numpy(), a[[4, 0, 4]])
+    assert all(np.array_equal(s._normals[k], c._normals[k][[4, 0, 4]]) for k in range(3))
+    assert all(np.array_equal(s._colors[k], c._colors[k][[4, 0, 4]]) for k in range(3))
+    assert s._colors[0].dtype == np.uint8 and np.array_equal(s._intensity, c._intensity[[4, 0, 4]])
+    inv = c.select_inverse([1, 2])
+    assert np.array_equal(inv._intensity, c._intensity[[0, 3, 4, 5]])
+    assert np.array_equal(inv._colors[2], c._colors[2][[0, 3, 4, 5]])
+    plain = pc.PointCloud.from_numpy(a).select([1])
+    assert plain._normals is None and plain._colors is None and plain._intensity is None
+
+
 def test_argument_validation_matches_reference():
     c = pc.PointCloud.from_numpy(np.zeros((2, 3), dtype=np.float32))
     for bad in (float("nan"), float("inf"), -1.0):

@@ -119,6 +119,19 @@ int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const
 int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy, const float *dqz,
                           size_t n, float radius, uint32_t *dcount);
 
+/* KdTree::radius_search for a batch of queries — kdtree.rs:105-135.  CSR result:
+ * indices[offsets[i] .. offsets[i+1]) = the points with d2 <= radius*radius of query i in
+ * ascending index order (kdtree.rs:131-132); offsets[n+1].  *total receives the number of
+ * results.  When they do not fit `capacity` (or indices is NULL) the call returns
+ * PCRS_ERR_INVALID_ARG with offsets and *total filled in, so that the caller can size the list
+ * and call again; more than 2^32-2 results in one call are refused the same way. */
+int pcrs_radius_search(pcrs_index *index, const float *qx, const float *qy, const float *qz,
+                       size_t n, float radius, uint32_t *offsets, uint32_t *indices,
+                       size_t capacity, size_t *total);
+int pcrs_radius_search_dev(pcrs_index *index, const float *dqx, const float *dqy,
+                           const float *dqz, size_t n, float radius, uint32_t *doffsets,
+                           uint32_t *dindices, size_t capacity, size_t *total);
+
 /* radius_outlier_removal — crates/filters/src/radius_outlier.rs:4-18: keep[i] = 1
  * when at least min_neighbors points of the cloud (point i itself included) lie
  * within `radius` of point i.  As in KdTree::radius_search (kdtree.rs:105-135) a

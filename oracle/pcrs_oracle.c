@@ -497,6 +497,32 @@ size_t orc_radius_outlier(const float *x, const float *y, const float *z, size_t
     return kept;
 }
 
+/* KdTree::radius_search for a batch of queries (kdtree.rs:105-135): for query i the indices of
+ * the finite points with d2 <= radius*radius in ascending order (:131-132) at
+ * indices[offsets[i] .. offsets[i+1]).  Nothing for an empty cloud, radius <= 0 or non-finite, or
+ * a non-finite query (:106-112).  Lists are written while they fit into `capacity`; the return
+ * value is the total number of results either way. */
+size_t orc_radius_search(const float *x, const float *y, const float *z, size_t m, const float *qx,
+                         const float *qy, const float *qz, size_t n, float radius,
+                         uint32_t *offsets, uint32_t *indices, size_t capacity) {
+    int ok = m > 0 && radius > 0.0f && isfinite(radius);
+    float r2 = radius * radius; /* kdtree.rs:114 */
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        offsets[i] = (uint32_t)total;
+        if (!ok || !finite3(qx[i], qy[i], qz[i])) continue;
+        for (size_t j = 0; j < m; ++j) {
+            if (!finite3(x[j], y[j], z[j])) continue;
+            if (sqdist(qx[i], qy[i], qz[i], x[j], y[j], z[j]) <= r2) { /* kdtree.rs:127 */
+                if (total < capacity) indices[total] = (uint32_t)j;
+                ++total;
+            }
+        }
+    }
+    offsets[n] = (uint32_t)total;
+    return total;
+}
+
 /* ------------------------------------------------------------------ */
 /* voxel_downsample (crates/filters/src/voxel_downsample.rs:12-65)     */
 /* ------------------------------------------------------------------ */

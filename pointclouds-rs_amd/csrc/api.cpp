@@ -575,6 +575,102 @@ int pcrs_radius_count(pcrs_index *index, const float *qx, const float *qy, const
     return pcrs_on_exception(index ? index->ctx : nullptr);
 }
 
+// KdTree::radius_search for a batch (kdtree.rs:105-135): count, scan, fill, order.
+int pcrs_radius_search_dev(pcrs_index *index, const float *dqx, const float *dqy,
+                           const float *dqz, size_t n, float radius, uint32_t *doffsets,
+                           uint32_t *dindices, size_t capacity, size_t *total) try {
+    if (!index || !doffsets || !total) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    *total = 0;
+    if (n >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    // pass 1: the counts, scanned in place into offsets[0..n], the total also in 64 bits
+    PCRS_TRY(pcrs_radius_count_dev(index, dqx, dqy, dqz, n, radius, doffsets));
+    DevBuf sums, tot64;
+    PCRS_HIP_CHECK(ctx, sums.alloc(ctx, (n / 1024 + 4) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, tot64.alloc(ctx, sizeof(unsigned long long)));
+    PCRS_TRY(pcrs_launch_sum_u32(ctx, doffsets, n, tot64.as<unsigned long long>()));
+    if (n)
+        PCRS_TRY(pcrs_launch_scan_u32(ctx, doffsets, n, sums.as<uint32_t>(), doffsets + n));
+    else
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(doffsets, 0, sizeof(uint32_t), ctx->stream));
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &pin));
+    PCRS_TRY(pcrs_launch_publish(ctx, tot64.p, pin, sizeof(unsigned long long)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long t = *reinterpret_cast<unsigned long long *>(pin);
+    *total = (size_t)t;
+    if (t >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG,
+                            "%llu results do not fit 32-bit offsets: search fewer queries at a time", t);
+    if (t == 0) return PCRS_OK;
+    if (t > capacity || !dindices)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG,
+                            "the index list needs room for %llu entries (capacity %zu)", t, capacity);
+    // pass 2 (a usable radius and a non-empty cloud, or there would be no results)
+    if (pcrs_grid_radius_ok(index, radius)) {
+        // the grid meets a query's hits in cell order: keyed by (query, index) and sorted, every
+        // list is ascending (kdtree.rs:131-132) and stays where the offsets put it
+        int idx_bits = 1, q_bits = 1;
+        while (idx_bits < 32 && (index->m >> idx_bits)) ++idx_bits;
+        while (q_bits < 32 && (n >> q_bits)) ++q_bits;
+        DevBuf keys, keys_alt, vals, vals_alt;
+        PCRS_HIP_CHECK(ctx, keys.alloc(ctx, t * sizeof(uint64_t)));
+        PCRS_HIP_CHECK(ctx, keys_alt.alloc(ctx, t * sizeof(uint64_t)));
+        PCRS_HIP_CHECK(ctx, vals.alloc(ctx, t * sizeof(uint32_t)));
+        PCRS_HIP_CHECK(ctx, vals_alt.alloc(ctx, t * sizeof(uint32_t)));
+        KnnQuery q;
+        q.qx = dqx;
+        q.qy = dqy;
+        q.qz = dqz;
+        q.nq = n;
+        PCRS_TRY(pcrs_launch_radius_fill_grid(index, q, radius, doffsets, keys.as<uint64_t>(),
+                                              idx_bits));
+        bool in_alt = false;
+        PCRS_TRY(pcrs_sort_pairs_u64(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(),
+                                     keys_alt.as<uint64_t>(), vals_alt.as<uint32_t>(), (size_t)t,
+                                     idx_bits + q_bits, &in_alt));
+        PCRS_TRY(pcrs_launch_key_low_bits(ctx, in_alt ? keys_alt.as<uint64_t>() : keys.as<uint64_t>(),
+                                          (size_t)t, idx_bits, dindices));
+        return PCRS_OK;
+    }
+    return pcrs_launch_radius_fill(ctx, index->x, index->y, index->z, index->m, dqx, dqy, dqz, n,
+                                   radius, doffsets, dindices);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
+}
+
+int pcrs_radius_search(pcrs_index *index, const float *qx, const float *qy, const float *qz,
+                       size_t n, float radius, uint32_t *offsets, uint32_t *indices,
+                       size_t capacity, size_t *total) try {
+    if (!index || !offsets || !total) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    *total = 0;
+    if (n == 0) {
+        offsets[0] = 0;
+        return PCRS_OK;
+    }
+    if (!qx || !qy || !qz) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    DevBuf dqx, dqy, dqz, doff, dind;
+    PCRS_TRY(upload(ctx, dqx, qx, n));
+    PCRS_TRY(upload(ctx, dqy, qy, n));
+    PCRS_TRY(upload(ctx, dqz, qz, n));
+    PCRS_HIP_CHECK(ctx, doff.alloc(ctx, (n + 1) * sizeof(uint32_t)));
+    if (indices && capacity) PCRS_HIP_CHECK(ctx, dind.alloc(ctx, capacity * sizeof(uint32_t)));
+    const int rc = pcrs_radius_search_dev(index, dqx.as<float>(), dqy.as<float>(), dqz.as<float>(),
+                                          n, radius, doff.as<uint32_t>(), dind.as<uint32_t>(),
+                                          dind.p ? capacity : 0, total);
+    // the offsets are valid even when the list did not fit: the caller learns every list length
+    PCRS_TRY(download(ctx, offsets, doff.p, (n + 1) * sizeof(uint32_t)));
+    if (rc == PCRS_OK && *total) PCRS_TRY(download(ctx, indices, dind.p, *total * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
+}
+
 int pcrs_voxel_downsample_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
                               size_t n, float voxel_size, float *dout_x, float *dout_y,
                               float *dout_z, size_t *n_out) try {
@@ -1236,15 +1332,13 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
                           const float *tny, const float *tnz, float max_d, uint32_t *nn_idx,
                           float *nn_d2, double *dsums, uint32_t *tgt_out, float *dist_out,
                           const IcpTail &tail = IcpTail(), bool coherent = false,
-                          float *const *writable = nullptr, unsigned retry_hint = 0,
-                          const uint32_t **fail_count_dev = nullptr) {
+                          float *const *writable = nullptr) {
     KnnQuery q;
     q.qx = cx;
     q.qy = cy;
     q.qz = cz;
     q.nq = n;
     q.coherent = coherent;
-    q.retry_blocks_hint = retry_hint;
     if (writable && tail.state) {  // the increment of the previous iteration is still to be applied
         q.xform = tail.state;
         q.wx = writable[0];
@@ -1257,7 +1351,6 @@ int correspond_and_reduce(pcrs_ctx *ctx, pcrs_index *target, int mode, const flo
     o.nn_idx = nn_idx;
     o.nn_d2 = nn_d2;
     PCRS_TRY(run_query(target, q, o, 1));
-    if (fail_count_dev) *fail_count_dev = q.fail_count_dev;
     return pcrs_launch_icp_reduce(ctx, mode, cx, cy, cz, n, target->x, target->y, target->z, tnx,
                                   tny, tnz, nn_idx, nn_d2, max_d, tgt_out, dist_out, dsums, tail);
 }
@@ -1308,15 +1401,12 @@ int icp_alloc_work(pcrs_icp *icp) {
 }
 
 // Fresh loop state on the device (identity transform, no previous rmse).  *hs: pinned host copy
-// that the read-backs of the loop land in; *hfail: a pinned word behind it.
-int icp_state_init(pcrs_icp *icp, IcpLoopState **hs_out, uint32_t **hfail_out, IcpLoopState **ds_out) {
+// that the read-backs of the loop land in.
+int icp_state_init(pcrs_icp *icp, IcpLoopState **hs_out, IcpLoopState **ds_out) {
     pcrs_ctx *ctx = icp->ctx;
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(IcpLoopState) + 64, &pin));
     IcpLoopState *hs = reinterpret_cast<IcpLoopState *>(pin);
-    uint32_t *hfail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pin) +
-                                                   ((sizeof(IcpLoopState) + 15) & ~(size_t)15));
-    *hfail = 0;
     std::memset(hs, 0, sizeof(*hs));
     hs->cum_r[0] = hs->cum_r[4] = hs->cum_r[8] = 1.0f;
     hs->inc_r[0] = hs->inc_r[4] = hs->inc_r[8] = 1.0f;
@@ -1325,7 +1415,6 @@ int icp_state_init(pcrs_icp *icp, IcpLoopState **hs_out, uint32_t **hfail_out, I
     PCRS_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, sizeof(*hs), hipMemcpyHostToDevice, ctx->stream));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // hs is reused for the read-backs
     *hs_out = hs;
-    *hfail_out = hfail;
     *ds_out = ds;
     return PCRS_OK;
 }
@@ -1601,8 +1690,7 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     // The loop state lives on the device (icp_tail_step carries icp.rs:147-188), so the host only
     // looks at it every few iterations; iterations queued behind the end of the loop are no-ops.
     IcpLoopState *hs = nullptr, *ds = nullptr;
-    uint32_t *hfail = nullptr;
-    PCRS_TRY(icp_state_init(icp, &hs, &hfail, &ds));
+    PCRS_TRY(icp_state_init(icp, &hs, &ds));
     float *cx = icp->cur[0].as<float>(), *cy = icp->cur[1].as<float>(), *cz = icp->cur[2].as<float>();
     // The convergence test |prev_rmse - rmse| < tolerance (icp.rs:173) can only fire for a
     // positive tolerance.  Then every iteration takes its rmse from the reference's own sum
@@ -1619,8 +1707,6 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
     tail.seq_work = reinterpret_cast<char *>(icp->seq_work.p) + icp->seq_scalars_bytes;
     tail.seq_work_bytes = icp->seq_work.bytes - icp->seq_scalars_bytes;
     float *const cur_w[3] = {cx, cy, cz};
-    unsigned retry_hint = 0;                 // retry-stage grid of the searches (0 = worst case)
-    const uint32_t *fail_count_dev = nullptr;  // the last search's "left after stage 1" counter
     // icp.rs:186 (current <- increment(current)) is not a launch of its own: the search of the
     // next iteration applies the pending increment as it loads its queries
     auto iteration = [&](uint32_t it) {
@@ -1629,28 +1715,27 @@ int pcrs_icp_run(pcrs_icp *icp, int mode, uint32_t max_iterations, float toleran
                                      icp->tnz, max_correspondence_distance,
                                      icp->nn_idx.as<uint32_t>(), icp->nn_d2.as<float>(),
                                      icp->sums.as<double>(), nullptr, nullptr, tail,
-                                     icp->perm.p != nullptr, it > 0 ? cur_w : nullptr, retry_hint,
-                                     &fail_count_dev);
+                                     icp->perm.p != nullptr, it > 0 ? cur_w : nullptr);
     };
     if (max_iterations == 0) {  // icp.rs:190-197: one metrics pass, identity transform
         tail.metrics_only = true;
         tail.exact = true;
         PCRS_TRY(iteration(0));
     }
-    constexpr uint32_t kBatch = 4;
+    // Iterations are queued in batches and the state is looked at after each: four at a time for
+    // the first sixteen, then eight (registrations that converge do so early, and an iteration
+    // queued behind the end of the loop still costs its launches -- with a live tolerance also
+    // the f32 sum's, which does not look at the flag; long runs pay for a read-back only every
+    // eighth iteration).
     for (uint32_t iter = 0; iter < max_iterations;) {
-        const uint32_t nb = std::min(kBatch, max_iterations - iter);
+        const uint32_t batch = iter < 16u ? 4u : 8u;
+        const uint32_t nb = std::min(batch, max_iterations - iter);
         for (uint32_t j = 0; j < nb; ++j)
             PCRS_TRY(iteration(iter + j));  // [pending increment,] search, reduction, tail
         iter += nb;
         PCRS_TRY(pcrs_launch_publish(ctx, ds, hs, sizeof(*hs)));  // hs is pinned
-        if (fail_count_dev) PCRS_TRY(pcrs_launch_publish(ctx, fail_count_dev, hfail, sizeof(uint32_t)));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done) break;
-        // The retry stage reads its work from device memory, so its grid may be any size: what the
-        // last search left over (with room to double) instead of the worst case spares most of an
-        // empty launch once the clouds are nearly aligned.
-        if (fail_count_dev) retry_hint = std::max(64u, (*hfail + 1u) / 2u);
     }
     // the increment of the last iteration (a no-op once the loop has ended on its own)
     if (max_iterations > 0) PCRS_TRY(pcrs_launch_transform_state(ctx, cx, cy, cz, icp->n, ds));
@@ -1696,8 +1781,7 @@ int pcrs_icp_shard_begin(pcrs_icp *icp, size_t n_source_total) try {
     if (icp->m == 0) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "empty target");
     PCRS_TRY(pcrs_icp_reset(icp));
     IcpLoopState *hs = nullptr, *ds = nullptr;
-    uint32_t *hfail = nullptr;
-    PCRS_TRY(icp_state_init(icp, &hs, &hfail, &ds));
+    PCRS_TRY(icp_state_init(icp, &hs, &ds));
     icp->shard_total = n_source_total;
     PCRS_HIP_CHECK(ctx, icp->shard_seq.alloc(ctx, icp->seq_scalars_bytes +
                                                       pcrs_sor_stats_workspace(n_source_total)));

@@ -441,6 +441,7 @@ struct CellArgs {
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
+    uint32_t *stage1_fail;  // 1-NN kernel (it retries in place): counts what its first stage left
     uint32_t kcert;         // neighbours that must be certified (<= K)
     uint32_t kcollect;      // neighbours whose identity is needed (pass 2), 0 = none
     uint32_t *zero_me;      // first-stage kernels: 16 words to clear (the next search's counters)
@@ -744,7 +745,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 // (ds_bpermute), so a box of many short rows — a surface seen through a large cube — costs a few
 // full-width steps instead of one step per row.  Four steps are requested before any is used: a
 // retried query is a single wave, so nothing else hides its load latency.
-template <class F>
+template <int DEPTH_ALL = 8, int DEPTH = 4, class F>
 __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int y0, int y1, int z0,
                                           int z1, int lane, F f) {
     const GridGeom &g = a.g;
@@ -753,15 +754,15 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
     const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1) {
         // the whole grid is the whole sorted array: a linear scan, eight steps in flight
-        for (uint32_t t0 = 0; t0 < a.nvalid; t0 += 8 * 64) {
-            float4 p[8];
+        for (uint32_t t0 = 0; t0 < a.nvalid; t0 += DEPTH_ALL * 64) {
+            float4 p[DEPTH_ALL];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < DEPTH_ALL; ++j) {
                 const uint32_t t = t0 + j * 64 + lane;
                 p[j] = t < a.nvalid ? a.spts[t] : zero;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < DEPTH_ALL; ++j)
                 if (t0 + j * 64 < a.nvalid) f(p[j], t0 + j * 64 + lane < a.nvalid, t0 + j * 64 + lane);
         }
         return;
@@ -783,12 +784,12 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
         }
         const uint32_t pre = incl - len;  // list position of this lane's row
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        for (uint32_t t0 = 0; t0 < total; t0 += 4 * 64) {
-            uint32_t slot[4];
-            bool v[4];
-            float4 p[4];
+        for (uint32_t t0 = 0; t0 < total; t0 += DEPTH * 64) {
+            uint32_t slot[DEPTH];
+            bool v[DEPTH];
+            float4 p[DEPTH];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < DEPTH; ++j) {
                 const uint32_t t = t0 + j * 64 + lane;
                 int lo = 0;  // the last row whose list position is <= t (empty rows share theirs)
 #pragma unroll
@@ -801,7 +802,7 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
                 p[j] = v[j] ? a.spts[slot[j]] : zero;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < DEPTH; ++j)
                 if (t0 + j * 64 < total) f(p[j], v[j], slot[j]);
         }
     }
@@ -1070,6 +1071,80 @@ __global__ __launch_bounds__(GB_THREADS) void owned_write_kernel(const float4 *s
         if (f & (1u << i)) list[at++] = first + i;
 }
 
+// 1-NN retry of ONE query by a whole wave (the K = 1 case of knn_wave_kernel as a function): cubes
+// of half-width a.wave_radii[...] in turn until the nearest point is certified, the whole grid
+// last where the launch allows it.  Lane 0 stores the answer; a query that stays uncertified goes
+// to a.fail_list for the brute-force stage.  entry: query index, PCRS_HEAVY_FLAG set when the
+// 27-cell cube itself is still to be searched.
+__device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &out, uint32_t entry,
+                                               float qx, float qy, float qz, int lane) {
+    const GridGeom &g = a.g;
+    const uint32_t qi = entry & ~PCRS_HEAVY_FLAG;
+    const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+    const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
+    const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
+    const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+    uint64_t best = PCRS_EMPTY_KEY;
+    float best_d2 = __builtin_inff();
+    bool certified = false;
+#pragma unroll 1
+    for (int ri = (entry & PCRS_HEAVY_FLAG) ? 0 : 1; ri < a.n_radii && !certified; ++ri) {
+        const int R = a.wave_radii[ri];
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+        const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+        const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+        best = PCRS_EMPTY_KEY;
+        best_d2 = __builtin_inff();
+        wave_walk<4, 2>(a, x0, x1, y0, y1, z0, z1, lane, [&](const float4 &p, bool valid, uint32_t) {
+            if (valid) {
+                const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+                if (d2 <= best_d2) {
+                    const uint64_t k = make_key(d2, __float_as_uint(p.w));
+                    if (k < best) {
+                        best = k;
+                        best_d2 = d2;
+                    }
+                }
+            }
+        });
+        for (int r = 1; r < 64; r <<= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)best, r, 64);
+            const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), r, 64);
+            const uint64_t other = ((uint64_t)hi << 32) | lo;
+            if (other < best) best = other;
+        }
+        best_d2 = key_d2(best);
+        certified = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) && (z0 == 0) &&
+                    (z1 == g.nz - 1);
+        if (!certified) {
+            float margin = __builtin_inff();
+            const float u[3] = {ux, uy, uz};
+            const int c[3] = {cx, cy, cz};
+            const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                if (c[ax] + R < n[ax] - 1)
+                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+            }
+            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
+            certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
+                                       a.useful_d2 < (m * m) * (1.0f - 2e-6f));
+        }
+    }
+    if (lane != 0) return;
+    if (!certified) {
+        const uint32_t f = atomicAdd(a.fail_count, 1u);
+        a.fail_list[f] = qi;
+        return;
+    }
+    // beyond the caller's bound: not a usable neighbour (and possibly not the nearest)
+    const bool none = best == PCRS_EMPTY_KEY || best_d2 > a.useful_d2;
+    out.nn_idx[qi] = none ? PCRS_NO_INDEX : key_idx(best);
+    if (out.nn_d2) out.nn_d2[qi] = none ? __builtin_inff() : best_d2;
+}
+
 // 1-NN variant: a single pass tracking the best (d2, index) key, EIGHT LANES PER QUERY.  The
 // clouds this serves (ICP correspondences, ~1e5 queries) give a lane-per-query kernel barely one
 // wave per SIMD, each a long chain of dependent loads; eight lanes share the query's candidate
@@ -1218,52 +1293,68 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
                 if (t0 + j * NN_SUB < total_pts) visit(p[j]);
         }
         share();
-        if (sub != 0 || !active) continue;  // after the shuffles: one lane finishes the query
-        if (!qvalid) {
-            out.nn_idx[qi] = PCRS_NO_INDEX;
-            if (out.nn_d2) out.nn_d2[qi] = __builtin_inff();
-            continue;
-        }
-        if (diverted) {
-            const uint32_t f = atomicAdd(a.fail_count, 1u);
-            a.fail_list[f] = qi | PCRS_HEAVY_FLAG;
-            continue;
-        }
-        const int R = 1;
-        const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
-                           (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
-        bool certified = whole;
-        if (!whole) {
-            float margin = __builtin_inff();
-            const float u[3] = {ux, uy, uz};
-            const int c[3] = {cx, cy, cz};
-            const int n[3] = {g.nx, g.ny, g.nz};
+        // after the shuffles: one lane finishes the query; what it cannot finish is retried below
+        // by the whole wave, one query at a time
+        uint32_t retry = 0xFFFFFFFFu;  // entry for nn1_wave_retry, or none
+        if (sub == 0 && active) {
+            if (!qvalid) {
+                out.nn_idx[qi] = PCRS_NO_INDEX;
+                if (out.nn_d2) out.nn_d2[qi] = __builtin_inff();
+            } else if (diverted) {
+                retry = qi | PCRS_HEAVY_FLAG;
+            } else {
+                const int R = 1;
+                const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
+                                   (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
+                bool certified = whole;
+                if (!whole) {
+                    float margin = __builtin_inff();
+                    const float u[3] = {ux, uy, uz};
+                    const int c[3] = {cx, cy, cz};
+                    const int n[3] = {g.nx, g.ny, g.nz};
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                if (c[ax] + R < n[ax] - 1)
-                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (c[ax] - R > 0)
+                            margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                        if (c[ax] + R < n[ax] - 1)
+                            margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+                    }
+                    const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+                    const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
+                    // either the nearest point is certainly inside the cube, or everything outside
+                    // it is farther than the caller cares about
+                    certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
+                                               a.useful_d2 < (m * m) * (1.0f - 2e-6f));
+                }
+                if (!certified) {
+                    if (a.fail_list) retry = qi;
+                } else {
+                    // A query certified only because everything outside the cube is beyond the
+                    // caller's bound may hold a point of the cube that is neither within the bound
+                    // nor the nearest one: it has no neighbour the caller can use, and is stored
+                    // as such.
+                    const bool none = best == PCRS_EMPTY_KEY || best_d2 > a.useful_d2;
+                    out.nn_idx[qi] = none ? PCRS_NO_INDEX : key_idx(best);
+                    if (out.nn_d2) out.nn_d2[qi] = none ? __builtin_inff() : best_d2;
+                }
             }
-            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
-            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
-            // either the nearest point is certainly inside the cube, or everything outside it is
-            // farther than the caller cares about
-            certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
-                                       a.useful_d2 < (m * m) * (1.0f - 2e-6f));
         }
-        if (!certified) {
-            if (a.fail_list) {
-                const uint32_t f = atomicAdd(a.fail_count, 1u);
-                a.fail_list[f] = qi;
-            }
-            continue;
+        // Larger cubes for the queries of this wave that were not certified (or were too crowded
+        // for eight lanes), here and now: a retry kernel behind this one costs a launch and a
+        // wave lifetime in every ICP iteration, for a handful of queries.
+        unsigned long long todo = __ballot(retry != 0xFFFFFFFFu);
+        if (todo && a.stage1_fail && (threadIdx.x & 63u) == 0)
+            atomicAdd(a.stage1_fail, (uint32_t)__popcll(todo));
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            // the query is the same in every lane: as scalars it costs the retry no registers
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)retry, src);
+            const float fx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qx), src));
+            const float fy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qy), src));
+            const float fz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qz), src));
+            nn1_wave_retry(a, out, e, fx, fy, fz, (int)(threadIdx.x & 63u));
         }
-        // A query certified only because everything outside the cube is beyond the caller's
-        // bound may hold a point of the cube that is neither within the bound nor the nearest
-        // one: it has no neighbour the caller can use, and is stored as such.
-        const bool none = best == PCRS_EMPTY_KEY || best_d2 > a.useful_d2;
-        out.nn_idx[qi] = none ? PCRS_NO_INDEX : key_idx(best);
-        if (out.nn_d2) out.nn_d2[qi] = none ? __builtin_inff() : best_d2;
     }
 }
 
@@ -1271,8 +1362,13 @@ __global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut 
 // itself included when it is in the cloud): the cube of a.R cells around the query's cell covers
 // the ball, so one walk counts exactly.  qmode 0 (every sorted slot, output at the point's
 // original index) or 1 (explicit queries).
+// FILL: instead of counting, the hits are written as keys (query << idx_bits | point index) at
+// keys[offsets[query] ...] in walk order (a sort by key then orders every list by index).
+template <bool FILL>
 __global__ __launch_bounds__(GB_THREADS) void radius_cell_kernel(CellArgs a, float r2,
-                                                                 uint32_t *count) {
+                                                                 uint32_t *count,
+                                                                 const uint32_t *offsets,
+                                                                 uint64_t *keys, int idx_bits) {
     const GridGeom &g = a.g;
     for (uint32_t pos = blockIdx.x * GB_THREADS + threadIdx.x; pos < a.nq;
          pos += gridDim.x * GB_THREADS) {
@@ -1290,17 +1386,24 @@ __global__ __launch_bounds__(GB_THREADS) void radius_cell_kernel(CellArgs a, flo
             qz = a.qz[qi];
         }
         uint32_t c = 0;
+        uint32_t at = FILL ? offsets[qi] : 0u;
         if (finite3(qx, qy, qz)) {
             const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
             const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
             const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
             walk_cube(a, cx, cy, cz, [&](const float4 &p, const float4 *) {
-                c += (sqdist(qx, qy, qz, p.x, p.y, p.z) <= r2) ? 1u : 0u;
+                const bool hit = sqdist(qx, qy, qz, p.x, p.y, p.z) <= r2;
+                if (FILL) {
+                    if (hit) keys[at++] = ((uint64_t)qi << idx_bits) | __float_as_uint(p.w);
+                } else {
+                    c += hit ? 1u : 0u;
+                }
             });
         }
-        count[qi] = c;
+        if (!FILL) count[qi] = c;
     }
 }
+
 
 // Puts the points of every cell into ascending original-index order (one thread per cell; the
 // scatter's atomics leave them in arrival order).  Used where a reproducible point order matters.
@@ -1754,14 +1857,36 @@ int pcrs_launch_radius_count_grid(pcrs_index *ix, const KnnQuery &q, float radiu
         a.qz = q.qz;
     }
     a.nq = nq;
-    hipLaunchKernelGGL(radius_cell_kernel, dim3((nq + GB_THREADS - 1) / GB_THREADS),
-                       dim3(GB_THREADS), 0, ctx->stream, a, r2, count);
+    hipLaunchKernelGGL(radius_cell_kernel<false>, dim3((nq + GB_THREADS - 1) / GB_THREADS),
+                       dim3(GB_THREADS), 0, ctx->stream, a, r2, count, nullptr, nullptr, 0);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
 
-// In-place exclusive scan of data[0..n) (u32); *total_out (device) receives the grand total.
-// sums must hold n / 1024 + 2 words.
+// The second pass of a radius search over explicit queries: the hits of query i as keys
+// (i << idx_bits | point index) at keys[offsets[i] ...], in walk order.
+int pcrs_launch_radius_fill_grid(pcrs_index *ix, const KnnQuery &q, float radius,
+                                 const uint32_t *offsets, uint64_t *keys, int idx_bits) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (q.nq == 0) return PCRS_OK;
+    CellArgs a{};
+    a.g = ix->g;
+    a.cell_start = ix->cell_start.as<uint32_t>();
+    a.spts = ix->spts.as<float4>();
+    a.nvalid = (uint32_t)ix->nvalid;
+    a.R = radius_cells(ix, radius);
+    a.qmode = 1;
+    a.qx = q.qx;
+    a.qy = q.qy;
+    a.qz = q.qz;
+    a.nq = (uint32_t)q.nq;
+    hipLaunchKernelGGL(radius_cell_kernel<true>, dim3((a.nq + GB_THREADS - 1) / GB_THREADS),
+                       dim3(GB_THREADS), 0, ctx->stream, a, radius * radius, nullptr, offsets, keys,
+                       idx_bits);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
 int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums,
                          uint32_t *total_out) {
     if (n == 0) {
@@ -1957,7 +2082,32 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         a.wy = q.wy;
         a.wz = q.wz;
     }
-    q.fail_count_dev = &counters[0];
+    // one launch tries the cube half-widths 2, 4, 8 in turn for each failed query
+    a.wave_radii[0] = 1;
+    a.wave_radii[1] = 2;
+    a.wave_radii[2] = 4;
+    a.wave_radii[3] = 8;
+    a.n_radii = 4;
+    // Clouds of up to 4 M points end with the whole grid as the last "cube": for the queries that
+    // are left (points far from the cloud) one wave scanning every point costs far less than the
+    // tiled brute-force kernel, where a single lane would work through the whole cloud.  1-NN
+    // searches then need no brute-force launch at all; longer lists keep it for tie overflows and
+    // for floods of stray queries (all_gate).
+    const bool wave_all = ix->nvalid <= (size_t)4 << 20;
+    const bool wave_does_all = nn_only && wave_all;  // one neighbour: no list can overflow
+    a.all_gate = 0xFFFFFFFFu;
+    if (wave_all) {
+        a.wave_radii[4] = 1 << 20;
+        a.n_radii = 5;
+        if (!nn_only) a.all_gate = 65536u;
+    }
+    if (nn_only) {
+        // the 1-NN kernel retries in place (a wave per failed query, right behind the wave's own
+        // first stage): what it still cannot certify goes straight to the brute-force list
+        a.fail_list = listB;
+        a.fail_count = &counters[3];
+        a.stage1_fail = &counters[0];
+    }
     pcrs_timing_begin(ctx);
     launch(blocks1);
     pcrs_timing_end(ctx);
@@ -1982,33 +2132,15 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         PCRS_DISPATCH_K(kb, PCRS_WAVE_CALL)
 #undef PCRS_WAVE_CALL
     };
-    unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);
-    if (q.retry_blocks_hint) retry_blocks = std::min(retry_blocks, q.retry_blocks_hint);
-    // one launch tries the cube half-widths 2, 4, 8 in turn for each failed query
-    a.wave_radii[0] = 1;
-    a.wave_radii[1] = 2;
-    a.wave_radii[2] = 4;
-    a.wave_radii[3] = 8;
-    a.n_radii = 4;
-    // Clouds of up to 4 M points end with the whole grid as the last "cube": for the queries that
-    // are left (points far from the cloud) one wave scanning every point costs far less than the
-    // tiled brute-force kernel, where a single lane would work through the whole cloud.  1-NN
-    // searches then need no brute-force launch at all; longer lists keep it for tie overflows and
-    // for floods of stray queries (all_gate).
-    const bool wave_all = ix->nvalid <= (size_t)4 << 20;
-    const bool wave_does_all = nn_only && wave_all;  // one neighbour: no list can overflow
-    a.all_gate = 0xFFFFFFFFu;
-    if (wave_all) {
-        a.wave_radii[4] = 1 << 20;
-        a.n_radii = 5;
-        if (!nn_only) a.all_gate = 65536u;
+    if (!nn_only) {
+        unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);
+        a.qmode = 2;
+        a.qlist = listA;
+        a.qcount = &counters[0];
+        a.fail_list = listB;
+        a.fail_count = &counters[3];
+        launch_wave(retry_blocks);
     }
-    a.qmode = 2;
-    a.qlist = listA;
-    a.qcount = &counters[0];
-    a.fail_list = listB;
-    a.fail_count = &counters[3];
-    launch_wave(retry_blocks);
     uint32_t *src = listB;
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     // stage 4: brute force over what is left

@@ -71,12 +71,16 @@ __global__ __launch_bounds__(256) void transform_kernel(const float *x, const fl
 
 // ---------------------------------------------------------------------------------------------
 // Count of reference points with d2 <= r2 per query (kdtree.rs:114-129), LDS-tiled scan.
+// FILL: the hits are written to indices[offsets[query] ...] instead of being counted; the scan
+// runs in index order, so every list comes out ascending (kdtree.rs:131-132).
 constexpr int RC_TILE = 1024;
+template <bool FILL>
 __global__ __launch_bounds__(256) void radius_count_kernel(const float *rx, const float *ry,
                                                            const float *rz, uint32_t m,
                                                            const float *qx, const float *qy,
                                                            const float *qz, uint32_t n, float r2,
-                                                           uint32_t *count) {
+                                                           uint32_t *count, const uint32_t *offsets,
+                                                           uint32_t *indices) {
     __shared__ __attribute__((aligned(16))) float tx[RC_TILE];
     __shared__ __attribute__((aligned(16))) float ty[RC_TILE];
     __shared__ __attribute__((aligned(16))) float tz[RC_TILE];
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(256) void radius_count_kernel(const float *rx, cons
     }
     const bool qvalid = qi < n && finite3(x, y, z);
     uint32_t c = 0;
+    uint32_t at = (FILL && qi < n) ? offsets[qi] : 0u;
     for (uint32_t base = 0; base < m; base += RC_TILE) {
         __syncthreads();
         for (int t = tid; t < RC_TILE; t += 256) {
@@ -109,10 +114,14 @@ __global__ __launch_bounds__(256) void radius_count_kernel(const float *rx, cons
         const uint32_t lim = min((uint32_t)RC_TILE, m - base);
         for (uint32_t j = 0; j < lim; ++j) {
             const float d2 = sqdist(x, y, z, tx[j], ty[j], tz[j]);
-            c += (d2 <= r2) ? 1u : 0u;
+            if (FILL) {
+                if (qvalid && d2 <= r2) indices[at++] = base + j;
+            } else {
+                c += (d2 <= r2) ? 1u : 0u;
+            }
         }
     }
-    if (qi < n) count[qi] = qvalid ? c : 0u;
+    if (!FILL && qi < n) count[qi] = qvalid ? c : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,8 +380,61 @@ int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, co
         return PCRS_OK;
     }
     const float r2 = radius * radius;  // kdtree.rs:114
-    hipLaunchKernelGGL(radius_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       ctx->stream, rx, ry, rz, (uint32_t)m, qx, qy, qz, (uint32_t)n, r2, count);
+    hipLaunchKernelGGL(radius_count_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, rx, ry, rz, (uint32_t)m, qx, qy, qz, (uint32_t)n, r2, count,
+                       nullptr, nullptr);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// Second pass of a radius search by brute force: indices[offsets[i] ...] = the hits of query i,
+// ascending.  Only for a usable radius (the count pass has already dealt with the other cases).
+int pcrs_launch_radius_fill(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
+                            size_t m, const float *qx, const float *qy, const float *qz, size_t n,
+                            float radius, const uint32_t *offsets, uint32_t *indices) {
+    if (n == 0 || m == 0) return PCRS_OK;
+    hipLaunchKernelGGL(radius_count_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, rx, ry, rz, (uint32_t)m, qx, qy, qz, (uint32_t)n,
+                       radius * radius, nullptr, offsets, indices);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+namespace pcrs {
+// sum of n counts as a 64-bit total (a u32 scan cannot tell an overflow)
+__global__ __launch_bounds__(256) void sum_u32_kernel(const uint32_t *v, size_t n,
+                                                      unsigned long long *total) {
+    unsigned long long local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        local += v[i];
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, local);
+}
+// indices[i] = low idx_bits bits of keys[i]
+__global__ __launch_bounds__(256) void key_low_bits_kernel(const uint64_t *keys, size_t n,
+                                                           int idx_bits, uint32_t *indices) {
+    const uint64_t mask = (idx_bits >= 64) ? ~0ull : ((1ull << idx_bits) - 1ull);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        indices[i] = (uint32_t)(keys[i] & mask);
+}
+}  // namespace pcrs
+
+int pcrs_launch_sum_u32(pcrs_ctx *ctx, const uint32_t *v, size_t n, unsigned long long *d_total) {
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(*d_total), ctx->stream));
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(pcrs::sum_u32_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                       ctx->stream, v, n, d_total);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_key_low_bits(pcrs_ctx *ctx, const uint64_t *keys, size_t n, int idx_bits,
+                             uint32_t *indices) {
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(pcrs::key_low_bits_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                       ctx->stream, keys, n, idx_bits, indices);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

@@ -202,11 +202,6 @@ struct KnnQuery {
     const void *xform = nullptr;
     float *wx = nullptr, *wy = nullptr, *wz = nullptr;
     mutable bool xform_fused = false;
-    // blocks for the retry stage (0 = sized for the worst case); the stage reads its work from
-    // device memory in a grid-stride loop, so any size is correct
-    unsigned retry_blocks_hint = 0;
-    // receives the device address of this search's "queries left after the first stage" counter
-    mutable const uint32_t *fail_count_dev = nullptr;
 };
 
 // ---- brute force (knn_bf.hip)
@@ -224,6 +219,16 @@ bool pcrs_grid_radius_ok(const pcrs_index *ix, float radius);
 int pcrs_launch_radius_count_grid(pcrs_index *ix, const KnnQuery &q, float radius,
                                   uint32_t *count);
 // keep[i] = count[i] >= min_neighbors (radius_outlier.rs:13)
+// Second pass of a radius search (after the counts have been scanned into offsets): brute force
+// writes ascending indices, the grid writes keys (query << idx_bits | index) in walk order.
+int pcrs_launch_radius_fill(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
+                            size_t m, const float *qx, const float *qy, const float *qz, size_t n,
+                            float radius, const uint32_t *offsets, uint32_t *indices);
+int pcrs_launch_radius_fill_grid(pcrs_index *ix, const KnnQuery &q, float radius,
+                                 const uint32_t *offsets, uint64_t *keys, int idx_bits);
+int pcrs_launch_sum_u32(pcrs_ctx *ctx, const uint32_t *v, size_t n, unsigned long long *d_total);
+int pcrs_launch_key_low_bits(pcrs_ctx *ctx, const uint64_t *keys, size_t n, int idx_bits,
+                             uint32_t *indices);
 int pcrs_launch_count_mask(pcrs_ctx *ctx, const uint32_t *count, size_t n, size_t min_neighbors,
                            uint8_t *keep, unsigned long long *d_count);
 // In-place exclusive scan of data[0..n) (u32); *total_out (device) receives the grand total.

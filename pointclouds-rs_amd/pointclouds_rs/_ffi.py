@@ -61,6 +61,8 @@ SIGNATURES = {
     "pcrs_knn_batch_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, _V, _V, _V]),
     "pcrs_radius_count": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V]),
     "pcrs_radius_count_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V]),
+    "pcrs_radius_search": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V, _V, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pcrs_radius_search_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, _V, _V, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pcrs_radius_outlier": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float, C.c_size_t, _V, _V,
                                                    c_size_p]),
     "pcrs_voxel_downsample": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_float] + _F3 + [c_size_p]),

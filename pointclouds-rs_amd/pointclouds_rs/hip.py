@@ -89,6 +89,27 @@ class Index:
         )
         return count
 
+    def radius_search(self, qx, qy, qz, radius):
+        """Batched KdTree::radius_search (kdtree.rs:105-135) as CSR: (offsets[n+1], indices);
+        indices[offsets[i]:offsets[i+1]] are the points within `radius` of query i, ascending."""
+        qx, qy, qz = _col(qx), _col(qy), _col(qz)
+        n = len(qx)
+        offsets = np.zeros(n + 1, dtype=np.uint32)
+        total = C.c_size_t(0)
+        lib = self.ctx.lib
+        # first call sizes the list (it reports the total and returns INVALID_ARG when there
+        # are results and no room for them)
+        rc = lib.pcrs_radius_search(self.handle, _ptr(qx), _ptr(qy), _ptr(qz), n, float(radius),
+                                    _ptr(offsets), None, 0, C.byref(total))
+        if total.value == 0 or total.value >= 0xFFFFFFFF:
+            self.ctx.check(rc)
+            return offsets, np.empty(0, dtype=np.uint32)
+        indices = np.empty(total.value, dtype=np.uint32)
+        self.ctx.check(lib.pcrs_radius_search(self.handle, _ptr(qx), _ptr(qy), _ptr(qz), n,
+                                              float(radius), _ptr(offsets), _ptr(indices),
+                                              total.value, C.byref(total)))
+        return offsets, indices
+
     def find_correspondences(self, sx, sy, sz, max_distance=np.inf):
         """Dense find_correspondences: (tgt_idx[n] uint32 (NO_INDEX = none), dist[n], n_corr)."""
         sx, sy, sz = _col(sx), _col(sy), _col(sz)

@@ -115,6 +115,21 @@ class Oracle:
                                            _p(keep), _p(count))
         return keep.astype(bool), int(kept), count
 
+    def radius_search(self, x, y, z, qx, qy, qz, radius):
+        """(offsets[n+1], indices): ascending indices of the points within `radius` per query."""
+        x, y, z, qx, qy, qz = map(_f, (x, y, z, qx, qy, qz))
+        m, n = len(x), len(qx)
+        self.lib.orc_radius_search.restype = C.c_size_t
+        self.lib.orc_radius_search.argtypes = [_V, _V, _V, C.c_size_t, _V, _V, _V, C.c_size_t,
+                                               C.c_float, _V, _V, C.c_size_t]
+        offsets = np.zeros(n + 1, dtype=np.uint32)
+        total = self.lib.orc_radius_search(_p(x), _p(y), _p(z), m, _p(qx), _p(qy), _p(qz), n,
+                                           radius, _p(offsets), None, 0)
+        indices = np.zeros(max(total, 1), dtype=np.uint32)
+        self.lib.orc_radius_search(_p(x), _p(y), _p(z), m, _p(qx), _p(qy), _p(qz), n, radius,
+                                   _p(offsets), _p(indices), total)
+        return offsets, indices[:total]
+
     def voxel_downsample(self, x, y, z, voxel_size):
         x, y, z = map(_f, (x, y, z))
         n = len(x)

@@ -33,6 +33,12 @@ class OracleImpl:
         c = int(cnt[0])
         return list(idx[0, :c]), list(dist[0, :c])
 
+    def radius_search(self, cloud, q, r):
+        x, y, z = cloud
+        off, idx = self.o.radius_search(x, y, z, [q[0]], [q[1]], [q[2]], r)
+        assert off[0] == 0 and off[1] == len(idx)
+        return [int(i) for i in idx]
+
     def radius_count(self, cloud, q, r):
         x, y, z = cloud
         pts_x = np.concatenate([np.asarray(x, F), [F(q[0])]])
@@ -103,6 +109,13 @@ class HipImpl:
         if c == 0:
             return [], []
         return list(idx[0, :c]), list(dist[0, :c])
+
+    def radius_search(self, cloud, q, r):
+        ix = self.h.Index(*cloud, algo=self.algo)
+        off, idx = ix.radius_search([q[0]], [q[1]], [q[2]], r)
+        ix.close()
+        assert off[0] == 0 and off[1] == len(idx)
+        return [int(i) for i in idx]
 
     def radius_count(self, cloud, q, r):
         ix = self.h.Index(*cloud, algo=self.algo)
@@ -240,6 +253,7 @@ def case_knn_returns_expected_neighbors(impl):  # kdtree.rs:173-183
 
 def case_radius_search_finds_points(impl):  # kdtree.rs:186-192 -> results {0, 1}
     assert impl.radius_count(cols([0, 0.5, 2], [0] * 3, [0] * 3), (0, 0, 0), 0.75) == 2
+    assert impl.radius_search(cols([0, 0.5, 2], [0] * 3, [0] * 3), (0, 0, 0), 0.75) == [0, 1]
 
 
 def case_knn_empty_cloud(impl):  # kdtree.rs:195-201
@@ -259,10 +273,12 @@ def case_knn_nan_query(impl):  # kdtree.rs:213-219
 
 def case_radius_search_empty_cloud(impl):  # kdtree.rs:222-227
     assert impl.radius_count(cols([], [], []), (0, 0, 0), 10.0) == 0
+    assert impl.radius_search(cols([], [], []), (0, 0, 0), 10.0) == []
 
 
 def case_radius_search_negative_radius(impl):  # kdtree.rs:230-235
     assert impl.radius_count(cols([0], [0], [0]), (0, 0, 0), -1.0) == 0
+    assert impl.radius_search(cols([0], [0], [0]), (0, 0, 0), -1.0) == []
 
 
 def case_knn_k_larger_than_cloud(impl):  # kdtree.rs:238-243
@@ -278,6 +294,7 @@ def case_knn_distances_are_sorted(impl):  # kdtree.rs:246-253
 
 def case_radius_search_exact_boundary(impl):  # kdtree.rs:256-269 -> {0}
     assert impl.radius_count(cols([1, 5], [0] * 2, [0] * 2), (0, 0, 0), 1.0) == 1
+    assert impl.radius_search(cols([1, 5], [0] * 2, [0] * 2), (0, 0, 0), 1.0) == [0]
 
 
 def case_knn_at_most_k(impl):  # kdtree.rs:271-290 (proptest, sampled deterministically)

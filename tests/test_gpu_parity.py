@@ -174,6 +174,59 @@ def test_radius_count_grid_parity(hip, oracle):
     ix.close()
 
 
+def test_radius_search_lists_parity(hip, oracle):
+    """Batched KdTree::radius_search as CSR lists, identical to the oracle's: through the grid
+    (lists ordered by a key sort) and through the brute-force scan, cloud points and outside
+    points as queries, non-finite queries and points, unusable radii, lists that do not fit."""
+    ux, uy, uz = gen.uniform_cloud(20000, 5, 0, 10)
+    dx, dy, dz = gen.degenerate_cloud(300, 9)
+    x, y, z = np.concatenate([ux, dx]), np.concatenate([uy, dy]), np.concatenate([uz, dz])
+    qx = np.concatenate([x[:2000], np.array([-5, 15, 5, np.nan], dtype=F)])
+    qy = np.concatenate([y[:2000], np.array([5, 5, -20, 1], dtype=F)])
+    qz = np.concatenate([z[:2000], np.array([5, 12, 5, 1], dtype=F)])
+    ix = hip.Index(x, y, z, k_hint=16, algo=2)
+    for r in (0.05, 0.4, 0.9, 1.7, 6.0):  # the largest is answered by the brute-force scan
+        off, idx = ix.radius_search(qx, qy, qz, r)
+        roff, ridx = oracle.radius_search(x, y, z, qx, qy, qz, r)
+        assert np.array_equal(off, roff), r
+        assert np.array_equal(idx, ridx), r
+        assert np.array_equal(np.diff(off.astype(np.int64)), ix.radius_count(qx, qy, qz, r))
+    for r in (-1.0, 0.0, float("nan"), float("inf")):
+        off, idx = ix.radius_search(qx, qy, qz, r)
+        assert not off.any() and len(idx) == 0
+    off, idx = ix.radius_search([], [], [], 1.0)
+    assert list(off) == [0] and len(idx) == 0
+    # a list that does not fit: the call reports the sizes and fails without writing
+    import ctypes as C
+
+    from pointclouds_rs import _ffi
+
+    n = len(qx)
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    small = np.full(8, 0xABCDABCD, dtype=np.uint32)
+    total = C.c_size_t(0)
+    rc = ix.ctx.lib.pcrs_radius_search(ix.handle, qx.ctypes.data_as(C.c_void_p),
+                                       qy.ctypes.data_as(C.c_void_p), qz.ctypes.data_as(C.c_void_p),
+                                       n, 0.9, offsets.ctypes.data_as(C.c_void_p),
+                                       small.ctypes.data_as(C.c_void_p), len(small), C.byref(total))
+    roff, ridx = oracle.radius_search(x, y, z, qx, qy, qz, 0.9)
+    assert rc == _ffi.PCRS_ERR_INVALID_ARG and total.value == len(ridx)
+    assert np.array_equal(offsets, roff) and (small == 0xABCDABCD).all()
+    ix.close()
+    # a small cloud (brute-force index) and an empty one
+    sx, sy, sz = gen.degenerate_cloud(400, 2)
+    ix = hip.Index(sx, sy, sz)
+    for r in (0.3, 1.0, 2.5):
+        off, idx = ix.radius_search(sx, sy, sz, r)
+        roff, ridx = oracle.radius_search(sx, sy, sz, sx, sy, sz, r)
+        assert np.array_equal(off, roff) and np.array_equal(idx, ridx)
+    ix.close()
+    ix = hip.Index([], [], [])
+    off, idx = ix.radius_search([1.0], [2.0], [3.0], 5.0)
+    assert list(off) == [0, 0] and len(idx) == 0
+    ix.close()
+
+
 @pytest.mark.parametrize("n", [500, 30000], ids=["brute", "grid"])
 def test_radius_outlier_parity(hip, oracle, n):
     ux, uy, uz = gen.uniform_cloud(n, 21, 0, 20)

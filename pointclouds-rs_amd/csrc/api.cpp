@@ -1839,7 +1839,7 @@ int pcrs_icp_shard_update_dev(pcrs_icp *icp, int mode, const double *dsums_all, 
     tail.seq_work_bytes = icp->shard_seq.bytes - icp->seq_scalars_bytes;
     if (tail.exact)
         PCRS_TRY(pcrs_launch_seq_sum(ctx, dd2_all, icp->shard_total, tail.seq_scalars, tail.seq_work,
-                                     tail.seq_work_bytes));
+                                     tail.seq_work_bytes, &tail.state->done));
     return pcrs_launch_icp_shard_tail(ctx, mode, dsums_all, world, icp->sums.as<double>(), tail);
 } catch (...) {
     return pcrs_on_exception(icp ? icp->ctx : nullptr);

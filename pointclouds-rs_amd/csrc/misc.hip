@@ -606,7 +606,7 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
     if (st && tail.exact && !tail.sums_only) {
         // the reference's rmse: dist*dist summed left to right in f32, in source order
         PCRS_TRY(pcrs_launch_seq_sum(ctx, tail.d2seq, n, tail.seq_scalars, tail.seq_work,
-                                     tail.seq_work_bytes));
+                                     tail.seq_work_bytes, &st->done));
         PCRS_TRY(pcrs_launch_icp_tail(ctx, mode, d_sums, tail));
     }
     return PCRS_OK;

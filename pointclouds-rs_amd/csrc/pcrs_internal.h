@@ -350,9 +350,10 @@ int pcrs_launch_icp_reduce(pcrs_ctx *ctx, int mode, const float *cx, const float
 // SOR global statistics with the reference's left-to-right f32 summation, on the device (stats.hip)
 size_t pcrs_sor_stats_workspace(size_t n);
 // Left-to-right f32 sum of n non-negative values with the same machinery; the sum is the float at
-// byte pcrs_seq_sum_result_offset() of d_scalars.  Work space as for the statistics.
+// byte pcrs_seq_sum_result_offset() of d_scalars.  Work space as for the statistics.  skip
+// (nullable device word): non-zero turns every kernel of the sum into a no-op.
 int pcrs_launch_seq_sum(pcrs_ctx *ctx, const float *values, size_t n, void *d_scalars, void *d_work,
-                        size_t work_bytes);
+                        size_t work_bytes, const uint32_t *skip = nullptr);
 size_t pcrs_seq_sum_result_offset();
 size_t pcrs_sor_stats_scalars_bytes();
 int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,

@@ -68,7 +68,9 @@ template <int PASS>
 __global__ __launch_bounds__(256) void chunk_sums_kernel(const float *mean, size_t n,
                                                          const StatsScalars *sc, double *csum,
                                                          uint32_t *ccnt, float *cmax,
-                                                         uint32_t nchunks) {
+                                                         uint32_t nchunks,
+                                                         const uint32_t *skip) {
+    if (skip && *skip) return;  // the caller's loop has ended: nobody will read this sum
     const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= nchunks) return;
     const int lane = threadIdx.x & 63;
@@ -105,7 +107,9 @@ constexpr uint32_t ST_SCAN_SPAN = 4096;
 
 __global__ __launch_bounds__(1024) void chunk_scan_local_kernel(
     double *csum, const uint32_t *ccnt, const float *cmax, uint32_t nchunks, double *ssum,
-    unsigned long long *scnt, float *smax, StatsScalars *sc, int write_count) {
+    unsigned long long *scnt, float *smax, StatsScalars *sc, int write_count,
+    const uint32_t *skip) {
+    if (skip && *skip) return;
     __shared__ double wsum[16];
     __shared__ unsigned long long wcnt[16];
     __shared__ float wmax[16];
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(1024) void chunk_scan_local_kernel(
 
 __global__ __launch_bounds__(1024) void chunk_scan_base_kernel(
     double *csum, uint32_t nchunks, const double *ssum, const unsigned long long *scnt,
-    const float *smax, StatsScalars *sc, int write_count) {
+    const float *smax, StatsScalars *sc, int write_count, const uint32_t *skip) {
+    if (skip && *skip) return;
     __shared__ double wsum[16];
     __shared__ unsigned long long wcnt[16];
     __shared__ float wmax[16];
@@ -286,7 +291,9 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
                                                               const StatsScalars *sc,
                                                               const double *cpre, Composite *comp,
                                                               uint32_t chunk_begin,
-                                                              uint32_t chunk_end) {
+                                                              uint32_t chunk_end,
+                                                              const uint32_t *skip) {
+    if (skip && *skip) return;
     const uint32_t chunk = chunk_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= chunk_end) return;
     const int lane = threadIdx.x & 63;
@@ -350,7 +357,9 @@ template <int W>
 __global__ __launch_bounds__(64) void batch_composite_kernel(const Composite *comp,
                                                              Composite *bcomp,
                                                              uint32_t chunk_begin,
-                                                             uint32_t chunk_end) {
+                                                             uint32_t chunk_end,
+                                                             const uint32_t *skip) {
+    if (skip && *skip) return;
     constexpr int G = 4;
     const int lane = threadIdx.x;
     const uint32_t base = chunk_begin + blockIdx.x * (64u * G);
@@ -430,7 +439,9 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
                                                         const Composite *bcomp,
                                                         uint32_t chunk_begin, uint32_t nchunks,
                                                         bool last, float std_mul,
-                                                        const double *cpre) {
+                                                        const double *cpre,
+                                                        const uint32_t *skip) {
+    if (skip && *skip) return;
     // walks the chunks [chunk_begin, nchunks); the state crosses launches in sc->run
     constexpr int G = 4;
     constexpr uint32_t BATCH = 64u * G;
@@ -748,19 +759,19 @@ static int stats_window(size_t n);
 template <int PASS>
 static void run_pass(pcrs_ctx *ctx, int W, const float *dmean, size_t n, StatsScalars *sc,
                      const double *csum, Composite *comp, Composite *bcomp, uint32_t nchunks,
-                     float std_mul) {
+                     float std_mul, const uint32_t *skip) {
     constexpr uint32_t kBatch = 256;  // chunks per batch composite = per scan of the walker
     if (W == 1) {
         hipLaunchKernelGGL((chunk_composite_kernel<PASS, 1>), dim3((nchunks + 3) / 4), dim3(256), 0,
-                           ctx->stream, dmean, n, sc, csum, comp, 0u, nchunks);
+                           ctx->stream, dmean, n, sc, csum, comp, 0u, nchunks, skip);
         hipLaunchKernelGGL((batch_composite_kernel<1>), dim3((nchunks + kBatch - 1) / kBatch),
-                           dim3(64), 0, ctx->stream, comp, bcomp, 0u, nchunks);
+                           dim3(64), 0, ctx->stream, comp, bcomp, 0u, nchunks, skip);
         if (nchunks <= ST_STAGE_CHUNKS)
             hipLaunchKernelGGL((stats_walk_kernel<PASS, 1, true>), dim3(1), dim3(ST_STAGE_THREADS), 0, ctx->stream,
-                               dmean, n, sc, comp, bcomp, 0u, nchunks, true, std_mul, csum);
+                               dmean, n, sc, comp, bcomp, 0u, nchunks, true, std_mul, csum, skip);
         else
             hipLaunchKernelGGL((stats_walk_kernel<PASS, 1, false>), dim3(1), dim3(64), 0, ctx->stream,
-                               dmean, n, sc, comp, bcomp, 0u, nchunks, true, std_mul, csum);
+                               dmean, n, sc, comp, bcomp, 0u, nchunks, true, std_mul, csum, skip);
         return;
     }
     // Before element i the f32 sum s and the exact prefix p obey p / (1 + i 2^-24) <= s <=
@@ -772,11 +783,11 @@ static void run_pass(pcrs_ctx *ctx, int W, const float *dmean, size_t n, StatsSc
         const uint32_t len = c0 == 0 ? kFirst : kSection;
         c1 = c0 + len < nchunks ? c0 + len : nchunks;
         hipLaunchKernelGGL((chunk_composite_kernel<PASS, 4>), dim3((c1 - c0 + 3) / 4), dim3(256), 0,
-                           ctx->stream, dmean, n, sc, csum, comp, c0, c1);
+                           ctx->stream, dmean, n, sc, csum, comp, c0, c1, skip);
         hipLaunchKernelGGL((batch_composite_kernel<4>), dim3((c1 - c0 + kBatch - 1) / kBatch),
-                           dim3(64), 0, ctx->stream, comp, bcomp, c0, c1);
+                           dim3(64), 0, ctx->stream, comp, bcomp, c0, c1, skip);
         hipLaunchKernelGGL((stats_walk_kernel<PASS, 4, false>), dim3(1), dim3(64), 0, ctx->stream,
-                           dmean, n, sc, comp, bcomp, c0, c1, c1 == nchunks, std_mul, csum);
+                           dmean, n, sc, comp, bcomp, c0, c1, c1 == nchunks, std_mul, csum, skip);
     }
 }
 
@@ -818,15 +829,16 @@ static StatsWork carve_work(size_t n, void *d_work) {
 // chunk sums -> f64 prefix -> composites -> walk, for one pass
 template <int PASS>
 static void run_whole_pass(pcrs_ctx *ctx, const StatsWork &k, const float *v, size_t n,
-                           StatsScalars *sc, int write_count, float std_mul) {
+                           StatsScalars *sc, int write_count, float std_mul,
+                           const uint32_t *skip = nullptr) {
     hipLaunchKernelGGL(chunk_sums_kernel<PASS>, dim3((k.nchunks + 3) / 4), dim3(256), 0, ctx->stream,
-                       v, n, sc, k.csum, k.ccnt, k.cmax, k.nchunks);
+                       v, n, sc, k.csum, k.ccnt, k.cmax, k.nchunks, skip);
     hipLaunchKernelGGL(chunk_scan_local_kernel, dim3(k.nspans), dim3(1024), 0, ctx->stream, k.csum,
-                       k.ccnt, k.cmax, k.nchunks, k.ssum, k.scnt, k.smax, sc, write_count);
+                       k.ccnt, k.cmax, k.nchunks, k.ssum, k.scnt, k.smax, sc, write_count, skip);
     if (k.nspans > 1)
         hipLaunchKernelGGL(chunk_scan_base_kernel, dim3(k.nspans), dim3(1024), 0, ctx->stream,
-                           k.csum, k.nchunks, k.ssum, k.scnt, k.smax, sc, write_count);
-    run_pass<PASS>(ctx, k.W, v, n, sc, k.csum, k.comp, k.bcomp, k.nchunks, std_mul);
+                           k.csum, k.nchunks, k.ssum, k.scnt, k.smax, sc, write_count, skip);
+    run_pass<PASS>(ctx, k.W, v, n, sc, k.csum, k.comp, k.bcomp, k.nchunks, std_mul, skip);
 }
 
 // Runs both passes; leaves {mu, thr, sigma, has_finite, nf} in *d_scalars (device).  No host sync.
@@ -847,14 +859,14 @@ int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std
 // The left-to-right f32 sum of n non-negative values (what `iter().sum::<f32>()` gives), left in
 // the `run` field of *d_scalars; pcrs_seq_sum_result_offset() tells where that float lies.
 int pcrs_launch_seq_sum(pcrs_ctx *ctx, const float *values, size_t n, void *d_scalars, void *d_work,
-                        size_t work_bytes) {
+                        size_t work_bytes, const uint32_t *skip) {
     if (work_bytes < pcrs_sor_stats_workspace(n))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "stats workspace too small");
     StatsScalars *sc = reinterpret_cast<StatsScalars *>(d_scalars);
     PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
     if (n == 0) return PCRS_OK;
     const StatsWork k = carve_work(n, d_work);
-    run_whole_pass<3>(ctx, k, values, n, sc, 1, 0.0f);
+    run_whole_pass<3>(ctx, k, values, n, sc, 1, 0.0f, skip);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

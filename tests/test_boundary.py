@@ -54,6 +54,14 @@ def test_null_handles_are_rejected_without_a_gpu():
         "pcrs_icp_run": (None, 0, 5, 0.0, 1.0, C.byref(res)),
         "pcrs_icp_reset": (None,),
         "pcrs_icp_register": (None, 0, *f3, 8, *f3, 8, None, None, None, 0, 5, 0.0, 1.0, C.byref(res)),
+        "pcrs_radius_search": (None, *f3, 8, 1.0, u32, u32, 8, C.byref(n_out)),
+        "pcrs_radius_search_dev": (None, *f3, 8, 1.0, u32, u32, 8, C.byref(n_out)),
+        "pcrs_icp_shard_begin": (None, 8),
+        "pcrs_icp_shard_accumulate_dev": (None, 1, 1.0, 0, buf, C.byref(h)),
+        "pcrs_icp_shard_update_dev": (None, 1, buf, 2, 0.0, None, 0),
+        "pcrs_icp_shard_rmse_dev": (None, buf),
+        "pcrs_icp_shard_state": (None, C.byref(res), C.byref(ok), None),
+        "pcrs_icp_shard_finish": (None,),
     }
     for name, args in calls.items():
         rc = getattr(lib, name)(*args)

@@ -59,6 +59,10 @@ def test_random_clouds(hip, oracle, kind, seed):
     ridx, rdist, _, rcnt = oracle.knn(x, y, z, q[:, 0], q[:, 1], q[:, 2], k, algo=0)
     assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
     assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+    rr = float(rng.choice([0.05, 0.4, 2.0]))
+    off, lst = ix.radius_search(q[:, 0], q[:, 1], q[:, 2], rr)
+    roff, rlst = oracle.radius_search(x, y, z, q[:, 0], q[:, 1], q[:, 2], rr)
+    assert np.array_equal(off, roff) and np.array_equal(lst, rlst)
     t, d, nc = ix.find_correspondences(q[:, 0], q[:, 1], q[:, 2], 5.0)
     rt, rd, rnc = oracle.find_correspondences(q[:, 0], q[:, 1], q[:, 2], x, y, z, 5.0, algo=0)
     assert nc == rnc and np.array_equal(t, rt) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))

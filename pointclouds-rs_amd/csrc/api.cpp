@@ -1019,8 +1019,10 @@ static int select_launch(pcrs_ctx *ctx, const float *dmean_all, size_t n_all, fl
     unsigned long long *dcount = reinterpret_cast<unsigned long long *>(sc + sb);
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, sb + 64, &pin));
-    PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb));
-    PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount));
+    // the counter of the mask lies right behind the scalars and is cleared with them
+    PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb,
+                                   sb + sizeof(unsigned long long)));
+    PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount, true));
     PCRS_TRY(pcrs_launch_publish(ctx, sc, pin, sb + 64));
     pend->pin = pin;
     pend->sb = sb;
@@ -1076,13 +1078,13 @@ int pcrs_sor_select_static_dev(pcrs_ctx *ctx, const float *dmean_all, size_t n_a
                             (size_t)PCRS_SOR_SELECT_STATIC_MAX, n_all);
     char *sc = reinterpret_cast<char *>(ctx->static_scratch);  // the resolved device address
     unsigned long long *dcount = reinterpret_cast<unsigned long long *>(sc + sb);
-    // the array keeps the last call's contents: the scalars and the count are cleared by the two
-    // launchers, every other part of the work space is written before it is read
-    PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb));
+    // the array keeps the last call's contents: the scalars and the count behind them are
+    // cleared by the first kernel of the statistics (or by a memset when there are no means),
+    // every other part of the work space is written before it is read
+    PCRS_TRY(pcrs_launch_sor_stats(ctx, dmean_all, n_all, std_mul, sc, sc + sb + 64, wb,
+                                   sb + sizeof(unsigned long long)));
     if (n_all)  // with no means at all the mask is left alone, as in pcrs_sor_select_dev
-        PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount));
-    else
-        PCRS_HIP_CHECK(ctx, hipMemsetAsync(dcount, 0, sizeof(*dcount), ctx->stream));
+        PCRS_TRY(pcrs_launch_mask_dev_thr(ctx, dmean, n, sc, dkeep, dcount, true));
     return pcrs_launch_select_result(ctx, sc, dcount, dresult);
 } catch (...) {
     return pcrs_on_exception(ctx);

@@ -221,7 +221,15 @@ constexpr uint32_t FINE_MAX_SHIFT = 12;
 
 __global__ __launch_bounds__(GB_THREADS) void coarse_hist_kernel(const float *x, const float *y,
                                                                  const float *z, uint32_t m,
-                                                                 SortPlan sp, uint32_t *table) {
+                                                                 SortPlan sp, uint32_t *table,
+                                                                 uint32_t *zero_word,
+                                                                 uint32_t *zero_block) {
+    // the first kernel of a sort clears what the later ones accumulate into: the non-empty-cell
+    // counter (fine_sort_kernel) and, for an index, the 32 stage counters of its searches
+    if (blockIdx.x == 0) {
+        if (zero_word && threadIdx.x == 0) *zero_word = 0u;
+        if (zero_block && threadIdx.x < 32) zero_block[threadIdx.x] = 0u;
+    }
     extern __shared__ uint32_t hist[];
     for (uint32_t t = threadIdx.x; t < sp.nb; t += GB_THREADS) hist[t] = 0;
     __syncthreads();
@@ -1573,10 +1581,12 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
 static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                               uint32_t m, const SortPlan &sp, uint32_t *table, uint32_t *table_sums,
                               float4 *tmp, float4 *sorted, uint32_t *cell_start,
-                              uint32_t *d_nonempty, float *sorted3 = nullptr) {
+                              uint32_t *d_nonempty, float *sorted3 = nullptr,
+                              uint32_t *zero_block = nullptr) {
+    // *d_nonempty needs no clearing by the caller: the first kernel does it
     const size_t entries = (size_t)sp.nb * sp.nblk;
     hipLaunchKernelGGL(coarse_hist_kernel, dim3(sp.nblk), dim3(GB_THREADS), sp.nb * sizeof(uint32_t),
-                       ctx->stream, x, y, z, m, sp, table);
+                       ctx->stream, x, y, z, m, sp, table, d_nonempty, zero_block);
     const uint32_t tblocks = (uint32_t)((entries + SCAN_BLOCK - 1) / SCAN_BLOCK);
     hipLaunchKernelGGL(scan_block_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream, table,
                        (uint32_t)entries, table_sums);
@@ -1673,11 +1683,12 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
                 PCRS_HIP_CHECK(ctx, sorted.alloc(ctx, nvalid * sizeof(float4)));
                 if (want3) PCRS_HIP_CHECK(ctx, sorted3.alloc(ctx, nvalid * 3 * sizeof(float)));
             }
-            PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_nonempty, 0, sizeof(uint32_t), ctx->stream));
+            if (!ix->counters.p) PCRS_HIP_CHECK(ctx, ix->counters.alloc(ctx, 32 * sizeof(uint32_t)));
+            ix->counter_phase = 0;
             PCRS_TRY(run_two_level_sort(ctx, ix->x, ix->y, ix->z, m, sp, table.as<uint32_t>(),
                                         table_sums.as<uint32_t>(), tmp.as<float4>(),
                                         sorted.as<float4>(), counts.as<uint32_t>(), d_nonempty,
-                                        sorted3.as<float>()));
+                                        sorted3.as<float>(), ix->counters.as<uint32_t>()));
         } else {
             if (!cell_id.p) PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
             PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
@@ -2057,7 +2068,6 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
             PCRS_HIP_CHECK(ctx, q_sorted.alloc(ctx, (size_t)nq * sizeof(float4)));
             PCRS_HIP_CHECK(ctx, q_cells.alloc(ctx, ((size_t)ix->ncell + 8) * sizeof(uint32_t)));
             uint32_t *q_nonempty = q_cells.as<uint32_t>() + ix->ncell + 1;
-            PCRS_HIP_CHECK(ctx, hipMemsetAsync(q_nonempty, 0, sizeof(uint32_t), ctx->stream));
             PCRS_TRY(run_two_level_sort(ctx, q.qx, q.qy, q.qz, nq, sp, q_table.as<uint32_t>(),
                                         q_sums.as<uint32_t>(), q_tmp.as<float4>(),
                                         q_sorted.as<float4>(), q_cells.as<uint32_t>(), q_nonempty));

@@ -356,10 +356,14 @@ int pcrs_launch_seq_sum(pcrs_ctx *ctx, const float *values, size_t n, void *d_sc
                         size_t work_bytes, const uint32_t *skip = nullptr);
 size_t pcrs_seq_sum_result_offset();
 size_t pcrs_sor_stats_scalars_bytes();
+// clear_bytes: how much memory from d_scalars on is to start at zero (the scalars, and whatever
+// the caller keeps behind them, e.g. the mask's counter); the run's first kernel clears it.
 int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
-                          void *d_scalars, void *d_work, size_t work_bytes);
+                          void *d_scalars, void *d_work, size_t work_bytes, size_t clear_bytes = 0);
+// count_is_clear: *d_count is already zero (cleared together with the scalars)
 int pcrs_launch_mask_dev_thr(pcrs_ctx *ctx, const float *mean, size_t n, const void *d_scalars,
-                             uint8_t *keep, unsigned long long *d_count);
+                             uint8_t *keep, unsigned long long *d_count,
+                             bool count_is_clear = false);
 void pcrs_sor_stats_decode(const void *host_copy, float *mu, float *thr, int *has_finite);
 int pcrs_sor_threshold_impl(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
                             float *thr, int *has_finite);

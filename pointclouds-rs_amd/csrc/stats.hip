@@ -69,8 +69,13 @@ __global__ __launch_bounds__(256) void chunk_sums_kernel(const float *mean, size
                                                          const StatsScalars *sc, double *csum,
                                                          uint32_t *ccnt, float *cmax,
                                                          uint32_t nchunks,
-                                                         const uint32_t *skip) {
+                                                         const uint32_t *skip, uint32_t *zero_me,
+                                                         uint32_t zero_words) {
     if (skip && *skip) return;  // the caller's loop has ended: nobody will read this sum
+    // the first kernel of a run clears the run's scalars (no kernel of this launch reads them,
+    // every later one writes them): a memset launch less
+    if (zero_me && blockIdx.x == 0)
+        for (uint32_t t = threadIdx.x; t < zero_words; t += 256u) zero_me[t] = 0u;
     const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= nchunks) return;
     const int lane = threadIdx.x & 63;
@@ -830,9 +835,10 @@ static StatsWork carve_work(size_t n, void *d_work) {
 template <int PASS>
 static void run_whole_pass(pcrs_ctx *ctx, const StatsWork &k, const float *v, size_t n,
                            StatsScalars *sc, int write_count, float std_mul,
-                           const uint32_t *skip = nullptr) {
+                           const uint32_t *skip = nullptr, uint32_t zero_words = 0) {
     hipLaunchKernelGGL(chunk_sums_kernel<PASS>, dim3((k.nchunks + 3) / 4), dim3(256), 0, ctx->stream,
-                       v, n, sc, k.csum, k.ccnt, k.cmax, k.nchunks, skip);
+                       v, n, sc, k.csum, k.ccnt, k.cmax, k.nchunks, skip,
+                       zero_words ? reinterpret_cast<uint32_t *>(sc) : nullptr, zero_words);
     hipLaunchKernelGGL(chunk_scan_local_kernel, dim3(k.nspans), dim3(1024), 0, ctx->stream, k.csum,
                        k.ccnt, k.cmax, k.nchunks, k.ssum, k.scnt, k.smax, sc, write_count, skip);
     if (k.nspans > 1)
@@ -843,14 +849,19 @@ static void run_whole_pass(pcrs_ctx *ctx, const StatsWork &k, const float *v, si
 
 // Runs both passes; leaves {mu, thr, sigma, has_finite, nf} in *d_scalars (device).  No host sync.
 int pcrs_launch_sor_stats(pcrs_ctx *ctx, const float *dmean, size_t n, float std_mul,
-                          void *d_scalars, void *d_work, size_t work_bytes) {
+                          void *d_scalars, void *d_work, size_t work_bytes, size_t clear_bytes) {
     if (work_bytes < pcrs_sor_stats_workspace(n))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "stats workspace too small");
     StatsScalars *sc = reinterpret_cast<StatsScalars *>(d_scalars);
-    PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
-    if (n == 0) return PCRS_OK;
+    // clear_bytes from d_scalars on start at zero (at least the scalars themselves): cleared by
+    // the first kernel of the run, or by a memset when there is no kernel to run
+    if (clear_bytes < sizeof(StatsScalars)) clear_bytes = sizeof(StatsScalars);
+    if (n == 0) {
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, clear_bytes, ctx->stream));
+        return PCRS_OK;
+    }
     const StatsWork k = carve_work(n, d_work);
-    run_whole_pass<1>(ctx, k, dmean, n, sc, 1, std_mul);  // mean
+    run_whole_pass<1>(ctx, k, dmean, n, sc, 1, std_mul, nullptr, (uint32_t)((clear_bytes + 3) / 4));  // mean
     run_whole_pass<2>(ctx, k, dmean, n, sc, 0, std_mul);  // variance
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
@@ -863,10 +874,12 @@ int pcrs_launch_seq_sum(pcrs_ctx *ctx, const float *values, size_t n, void *d_sc
     if (work_bytes < pcrs_sor_stats_workspace(n))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "stats workspace too small");
     StatsScalars *sc = reinterpret_cast<StatsScalars *>(d_scalars);
-    PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
-    if (n == 0) return PCRS_OK;
+    if (n == 0) {
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, sizeof(StatsScalars), ctx->stream));
+        return PCRS_OK;
+    }
     const StatsWork k = carve_work(n, d_work);
-    run_whole_pass<3>(ctx, k, values, n, sc, 1, 0.0f, skip);
+    run_whole_pass<3>(ctx, k, values, n, sc, 1, 0.0f, skip, (uint32_t)(sizeof(StatsScalars) / 4));
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }
@@ -895,8 +908,9 @@ size_t pcrs_sor_stats_workspace(size_t n) {
 size_t pcrs_sor_stats_scalars_bytes() { return sizeof(StatsScalars); }
 
 int pcrs_launch_mask_dev_thr(pcrs_ctx *ctx, const float *mean, size_t n, const void *d_scalars,
-                             uint8_t *keep, unsigned long long *d_count) {
-    if (d_count) PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(*d_count), ctx->stream));
+                             uint8_t *keep, unsigned long long *d_count, bool count_is_clear) {
+    if (d_count && !count_is_clear)
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(*d_count), ctx->stream));
     if (n == 0) return PCRS_OK;
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > (size_t)ctx->num_cus) blocks = (size_t)ctx->num_cus;

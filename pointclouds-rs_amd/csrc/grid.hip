@@ -504,7 +504,8 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
     }
 }
 
-// The same walk over the 27-cell cube (R = 1) reading 12-byte points: f(point, slot).  The search
+// The same walk over the 27-cell cube (R = 1) reading 12-byte points: f(point, slot, live); a call
+// with live == false carries no point and must change nothing.  The search
 // is bound by what its per-lane candidate loads move through the L1 (TA busy 75 % of the kernel),
 // and a candidate without its index is a quarter smaller.
 struct pcrs_p3 {
@@ -532,12 +533,25 @@ __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, in
                 const pcrs_p3 p2 = pp[2];
                 const pcrs_p3 p3 = pp[3];
                 const uint32_t s = (uint32_t)(pp - base);
-                f(p0, s);
-                f(p1, s + 1);
-                f(p2, s + 2);
-                f(p3, s + 3);
+                f(p0, s, true);
+                f(p1, s + 1, true);
+                f(p2, s + 2, true);
+                f(p3, s + 3, true);
             }
-            for (; pp < pe; ++pp) f(*pp, (uint32_t)(pp - base));
+            // The one to three points that are left, in a single step with the missing ones
+            // switched off (their loads repeat the first point, so they stay inside the row): some
+            // lane of the wave nearly always has three left, and three trips through a
+            // one-point loop cost half as much again.
+            const uint32_t rem = (uint32_t)(pe - pp);
+            if (rem) {
+                const pcrs_p3 p0 = pp[0];
+                const pcrs_p3 p1 = pp[rem > 1u ? 1 : 0];
+                const pcrs_p3 p2 = pp[rem > 2u ? 2 : 0];
+                const uint32_t s = (uint32_t)(pp - base);
+                f(p0, s, true);
+                f(p1, s + 1, rem > 1u);
+                f(p2, s + 2, rem > 2u);
+            }
         }
     }
 }
@@ -606,8 +620,9 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 #pragma unroll
         for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
         const pcrs_f2 qxy = {qx, qy};
-        walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t) {
-            const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
+        walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t, bool live) {
+            float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
+            if (!live) d2 = __builtin_inff();  // passes through the chain without a trace
 #pragma unroll
             for (int s = K - 1; s > 0; --s) D[s] = __builtin_amdgcn_fmed3f(d2, D[s - 1], D[s]);
             D[0] = fminf(D[0], d2);
@@ -674,9 +689,9 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             for (int i = 0; i < K; ++i)
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
             uint32_t hits = 0;
-            walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t slot) {
+            walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t slot, bool live) {
                 const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
-                if (d2 <= tau) {
+                if (live && d2 <= tau) {
                     if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = slot;
                     ++hits;
                 }

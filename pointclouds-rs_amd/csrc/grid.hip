@@ -504,15 +504,19 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
     }
 }
 
-// The same walk over the 27-cell cube (R = 1) reading 12-byte points: f(point, slot, live); a call
-// with live == false carries no point and must change nothing.  The search
-// is bound by what its per-lane candidate loads move through the L1 (TA busy 75 % of the kernel),
-// and a candidate without its index is a quarter smaller.
+// The same walk over the 27-cell cube (R = 1) reading 12-byte points, four at a time:
+// f4(d2[4], first slot) for every full group of four consecutive points of a row, f1(point, slot,
+// live) for the one to three that are left (a call with live == false carries no point and must
+// change nothing).  The search is bound by vector-instruction issue, then by what its per-lane
+// candidate loads move through the L1 (TA busy 75 % of the kernel): a candidate without its index
+// is a quarter smaller, and four of them are three 16-byte loads whose dwords pair up for packed
+// arithmetic as they are (sqdist_pk4).
 struct pcrs_p3 {
     float x, y, z;
 };
-template <class F>
-__device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, int cz, F f) {
+template <class F4, class F1>
+__device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, int cz,
+                                           const pcrs_q3 &q, F4 f4, F1 f1) {
     const GridGeom &g = a.g;
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
     const pcrs_p3 *base = reinterpret_cast<const pcrs_p3 *>(a.spts3);
@@ -528,15 +532,11 @@ __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, in
             const pcrs_p3 *pp = base + s0;
             const pcrs_p3 *const pe = base + s1;
             for (; pp + 3 < pe; pp += 4) {
-                const pcrs_p3 p0 = pp[0];
-                const pcrs_p3 p1 = pp[1];
-                const pcrs_p3 p2 = pp[2];
-                const pcrs_p3 p3 = pp[3];
-                const uint32_t s = (uint32_t)(pp - base);
-                f(p0, s, true);
-                f(p1, s + 1, true);
-                f(p2, s + 2, true);
-                f(p3, s + 3, true);
+                const pcrs_f4u *v = reinterpret_cast<const pcrs_f4u *>(pp);
+                const pcrs_f4u va = v[0], vb = v[1], vc = v[2];
+                float d2[4];
+                sqdist_pk4(q, va, vb, vc, d2);
+                f4(d2, (uint32_t)(pp - base));
             }
             // The one to three points that are left, in a single step with the missing ones
             // switched off (their loads repeat the first point, so they stay inside the row): some
@@ -548,9 +548,9 @@ __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, in
                 const pcrs_p3 p1 = pp[rem > 1u ? 1 : 0];
                 const pcrs_p3 p2 = pp[rem > 2u ? 2 : 0];
                 const uint32_t s = (uint32_t)(pp - base);
-                f(p0, s, true);
-                f(p1, s + 1, rem > 1u);
-                f(p2, s + 2, rem > 2u);
+                f1(p0, s, true);
+                f1(p1, s + 1, rem > 1u);
+                f1(p2, s + 2, rem > 2u);
             }
         }
     }
@@ -620,13 +620,22 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 #pragma unroll
         for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
         const pcrs_f2 qxy = {qx, qy};
-        walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t, bool live) {
-            float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
-            if (!live) d2 = __builtin_inff();  // passes through the chain without a trace
+        const pcrs_q3 q3 = make_q3(qx, qy, qz);
+        auto insert = [&](float d2) {
 #pragma unroll
             for (int s = K - 1; s > 0; --s) D[s] = __builtin_amdgcn_fmed3f(d2, D[s - 1], D[s]);
             D[0] = fminf(D[0], d2);
-        });
+        };
+        walk_cube3(
+            a, cx, cy, cz, q3,
+            [&](const float(&d2)[4], uint32_t) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) insert(d2[j]);
+            },
+            [&](const pcrs_p3 &p, uint32_t, bool live) {
+                const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
+                insert(live ? d2 : __builtin_inff());  // +inf passes through without a trace
+            });
 
         // ---- certification: every point outside the cube is farther than `margin`
         const int R = a.R;
@@ -689,13 +698,22 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             for (int i = 0; i < K; ++i)
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
             uint32_t hits = 0;
-            walk_cube3(a, cx, cy, cz, [&](const pcrs_p3 &p, uint32_t slot, bool live) {
-                const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
-                if (live && d2 <= tau) {
+            auto take = [&](float d2, uint32_t slot) {
+                if (d2 <= tau) {
                     if (hits < (uint32_t)CAP) lst[hits][threadIdx.x] = slot;
                     ++hits;
                 }
-            });
+            };
+            walk_cube3(
+                a, cx, cy, cz, q3,
+                [&](const float(&d2)[4], uint32_t slot) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) take(d2[j], slot + j);
+                },
+                [&](const pcrs_p3 &p, uint32_t slot, bool live) {
+                    const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
+                    if (live) take(d2, slot);
+                });
             if (hits > (uint32_t)CAP) {  // too many ties at the K-th distance for the list
                 if (a.fail_list) {
                     const uint32_t f = atomicAdd(a.fail_count, 1u);

@@ -531,12 +531,13 @@ __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, in
             const uint32_t s1 = a.cell_start[row + x1 + 1];
             const pcrs_p3 *pp = base + s0;
             const pcrs_p3 *const pe = base + s1;
-            for (; pp + 3 < pe; pp += 4) {
+            uint32_t slot = s0;  // counted beside the pointer: (pp - base) is a division by 12
+            for (; pp + 3 < pe; pp += 4, slot += 4) {
                 const pcrs_f4u *v = reinterpret_cast<const pcrs_f4u *>(pp);
                 const pcrs_f4u va = v[0], vb = v[1], vc = v[2];
                 float d2[4];
                 sqdist_pk4(q, va, vb, vc, d2);
-                f4(d2, (uint32_t)(pp - base));
+                f4(d2, slot);
             }
             // The one to three points that are left, in a single step with the missing ones
             // switched off (their loads repeat the first point, so they stay inside the row): some
@@ -547,10 +548,9 @@ __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, in
                 const pcrs_p3 p0 = pp[0];
                 const pcrs_p3 p1 = pp[rem > 1u ? 1 : 0];
                 const pcrs_p3 p2 = pp[rem > 2u ? 2 : 0];
-                const uint32_t s = (uint32_t)(pp - base);
-                f1(p0, s, true);
-                f1(p1, s + 1, rem > 1u);
-                f1(p2, s + 2, rem > 2u);
+                f1(p0, slot, true);
+                f1(p1, slot + 1, rem > 1u);
+                f1(p2, slot + 2, rem > 2u);
             }
         }
     }

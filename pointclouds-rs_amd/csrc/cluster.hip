@@ -149,6 +149,48 @@ __global__ __launch_bounds__(256) void cluster_union_kernel(
     }
 }
 
+// The same unions with ONE WAVE PER POINT, for small inputs (a few thousand obstacle points of a
+// LiDAR frame in a handful of crowded cells): a thread per point is then a few dozen waves, each
+// a serial loop over hundreds of candidates with a chain of dependent loads behind every union;
+// here the 64 lanes of a wave share the point's candidates.  Which thread joins a pair, and in
+// which order, does not change the components that come out.
+__global__ __launch_bounds__(256) void cluster_union_wave_kernel(
+    const float *x, const float *y, const float *z, const uint8_t *flag, const uint32_t *cell_id,
+    const uint32_t *order, uint32_t nvalid, const uint32_t *first, const int *ux, const int *uy,
+    const int *uz, float r2, uint32_t *parent) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per sorted position
+    if (i >= nvalid) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ncells = cell_id[nvalid];
+    const uint32_t cell = cell_id[i] - (flag[i] ? 0u : 1u);
+    const uint32_t a = order[i];
+    const float ax = x[a], ay = y[a], az = z[a];
+    const long long cx = ux[cell], cy = uy[cell], cz = uz[cell];
+    uint32_t root = a;  // what this lane last saw as the root of a (see cluster_union_kernel)
+    auto join_range = [&](uint32_t from, uint32_t to) {
+        for (uint32_t j = from + lane; j < to; j += 64u) {
+            const uint32_t b = order[j];
+            const float dx = ax - x[b], dy = ay - y[b], dz = az - z[b];
+            if ((dx * dx + dy * dy) + dz * dz <= r2 && b != root && parent[b] != root)
+                root = uf_union(parent, a, b);  // :151-153
+        }
+    };
+    join_range(i + 1, first[cell + 1]);  // own cell: the points after this one (:148)
+    if (cell + 1 < ncells && ux[cell + 1] == cx && uy[cell + 1] == cy &&
+        (long long)uz[cell + 1] == cz + 1)
+        join_range(first[cell + 1], first[cell + 2]);
+    const int ox[4] = {1, 1, 1, 0}, oy[4] = {0, 1, -1, 1};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const long long tx = cx + ox[c], ty = cy + oy[c];
+        uint32_t t = cell_lower_bound(ux, uy, uz, ncells, tx, ty, cz - 1);
+        while (t < ncells && ux[t] == tx && uy[t] == ty && (long long)uz[t] <= cz + 1) {
+            join_range(first[t], first[t + 1]);
+            ++t;
+        }
+    }
+}
+
 // label = smallest index of the component, as the sort key
 __global__ __launch_bounds__(256) void cluster_label_kernel(uint32_t *parent, uint32_t n,
                                                             uint64_t *keys, uint32_t *vals) {
@@ -266,10 +308,17 @@ int pcrs_launch_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y,
                                cs.flag.as<uint8_t>(), cs.cell_id.as<uint32_t>(), cs.order, nv,
                                cs.k[0].as<int>(), cs.k[1].as<int>(), cs.k[2].as<int>(),
                                first.as<uint32_t>(), u[0].as<int>(), u[1].as<int>(), u[2].as<int>());
-            hipLaunchKernelGGL(cluster_union_kernel, dim3(vb), dim3(256), 0, ctx->stream, x, y, z,
-                               cs.flag.as<uint8_t>(), cs.cell_id.as<uint32_t>(), cs.order, nv,
-                               first.as<uint32_t>(), u[0].as<int>(), u[1].as<int>(), u[2].as<int>(),
-                               r2, parent.as<uint32_t>());
+            if (nv <= 65536u)  // few points: a wave each
+                hipLaunchKernelGGL(cluster_union_wave_kernel, dim3((nv + 3) / 4), dim3(256), 0,
+                                   ctx->stream, x, y, z, cs.flag.as<uint8_t>(),
+                                   cs.cell_id.as<uint32_t>(), cs.order, nv, first.as<uint32_t>(),
+                                   u[0].as<int>(), u[1].as<int>(), u[2].as<int>(), r2,
+                                   parent.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(cluster_union_kernel, dim3(vb), dim3(256), 0, ctx->stream, x, y, z,
+                                   cs.flag.as<uint8_t>(), cs.cell_id.as<uint32_t>(), cs.order, nv,
+                                   first.as<uint32_t>(), u[0].as<int>(), u[1].as<int>(),
+                                   u[2].as<int>(), r2, parent.as<uint32_t>());
             PCRS_HIP_CHECK(ctx, hipGetLastError());
         }
     }

@@ -124,6 +124,37 @@ __global__ __launch_bounds__(GB_THREADS) void cell_count_kernel(const float *x, 
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = GB_THREADS * SCAN_ITEMS;
 
+// Exclusive scan of a short array by ONE block (1024 threads, consecutive items per thread): the
+// three-launch scan below costs three launch latencies whatever the length, and the tables of the
+// sorts of a small cloud (a LiDAR frame after voxel down-sampling) have a few thousand entries.
+constexpr uint32_t SCAN_SMALL_MAX = 32768;
+__global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *data, uint32_t n,
+                                                          uint32_t *total_out) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t per = (n + 1023u) / 1024u;  // <= 32
+    const uint32_t b = threadIdx.x * per;
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < per; ++i) t += (b + i < n) ? data[b + i] : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = t;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - t;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (uint32_t i = 0; i < per; ++i) {
+        if (b + i < n) {
+            const uint32_t v = data[b + i];
+            data[b + i] = run;
+            run += v;
+        }
+    }
+    if (threadIdx.x == 1023 && total_out) *total_out = run;
+}
+
 __global__ __launch_bounds__(GB_THREADS) void scan_block_kernel(uint32_t *data, uint32_t n,
                                                                 uint32_t *block_sums) {
     __shared__ uint32_t wsum[GB_THREADS / 64];
@@ -1620,13 +1651,18 @@ static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, con
     const size_t entries = (size_t)sp.nb * sp.nblk;
     hipLaunchKernelGGL(coarse_hist_kernel, dim3(sp.nblk), dim3(GB_THREADS), sp.nb * sizeof(uint32_t),
                        ctx->stream, x, y, z, m, sp, table, d_nonempty, zero_block);
-    const uint32_t tblocks = (uint32_t)((entries + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    hipLaunchKernelGGL(scan_block_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream, table,
-                       (uint32_t)entries, table_sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, table_sums, tblocks,
-                       table + entries);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream, table,
-                       (uint32_t)entries, table_sums);
+    if (entries <= SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, table,
+                           (uint32_t)entries, table + entries);
+    } else {
+        const uint32_t tblocks = (uint32_t)((entries + SCAN_BLOCK - 1) / SCAN_BLOCK);
+        hipLaunchKernelGGL(scan_block_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream, table,
+                           (uint32_t)entries, table_sums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, table_sums,
+                           tblocks, table + entries);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(tblocks), dim3(GB_THREADS), 0, ctx->stream, table,
+                           (uint32_t)entries, table_sums);
+    }
     hipLaunchKernelGGL(coarse_scatter_kernel, dim3(sp.nblk), dim3(GB_THREADS),
                        sp.nb * sizeof(uint32_t), ctx->stream, x, y, z, m, sp, table, tmp);
     hipLaunchKernelGGL(fine_sort_kernel, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp, sp,
@@ -1938,6 +1974,12 @@ int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums
         return PCRS_OK;
     }
     if (n >= 0xFFFFFFFFull) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "scan too long");
+    if (n <= SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, data, (uint32_t)n,
+                           total_out);
+        PCRS_HIP_CHECK(ctx, hipGetLastError());
+        return PCRS_OK;
+    }
     const uint32_t nblocks = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(GB_THREADS), 0, ctx->stream, data,
                        (uint32_t)n, sums);

@@ -817,25 +817,36 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 // (ds_bpermute), so a box of many short rows — a surface seen through a large cube — costs a few
 // full-width steps instead of one step per row.  Four steps are requested before any is used: a
 // retried query is a single wave, so nothing else hides its load latency.
+// clip (r >= 0): only the cells that reach into the ball of radius r around the grid-relative
+// point (ux, uy, uz) — rows farther from it than r in y and z are dropped, the others cut in x to
+// the ball's chord; r must include the allowance for f32 cell assignment.  stride: every stride-th
+// point of the list only (a sample of the box).
+struct BallClip {
+    float ux, uy, uz, r;
+};
 template <int DEPTH_ALL = 8, int DEPTH = 4, class F>
 __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int y0, int y1, int z0,
-                                          int z1, int lane, F f) {
+                                          int z1, int lane, F f,
+                                          BallClip clip = BallClip{0.0f, 0.0f, 0.0f, -1.0f},
+                                          uint32_t stride = 1u) {
     const GridGeom &g = a.g;
     const int ny = y1 - y0 + 1;
     const int nrows = ny * (z1 - z0 + 1);
     const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1) {
+    if (clip.r < 0.0f && x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 &&
+        z1 == g.nz - 1) {
         // the whole grid is the whole sorted array: a linear scan, eight steps in flight
-        for (uint32_t t0 = 0; t0 < a.nvalid; t0 += DEPTH_ALL * 64) {
+        const uint32_t ns = (a.nvalid + stride - 1u) / stride;
+        for (uint32_t s0 = 0; s0 < ns; s0 += DEPTH_ALL * 64) {
             float4 p[DEPTH_ALL];
 #pragma unroll
             for (int j = 0; j < DEPTH_ALL; ++j) {
-                const uint32_t t = t0 + j * 64 + lane;
-                p[j] = t < a.nvalid ? a.spts[t] : zero;
+                const uint32_t sidx = s0 + j * 64 + lane;
+                p[j] = sidx < ns ? a.spts[sidx * stride] : zero;
             }
 #pragma unroll
             for (int j = 0; j < DEPTH_ALL; ++j)
-                if (t0 + j * 64 < a.nvalid) f(p[j], t0 + j * 64 + lane < a.nvalid, t0 + j * 64 + lane);
+                if (s0 + j * 64 < ns) f(p[j], s0 + j * 64 + lane < ns, (s0 + j * 64 + lane) * stride);
         }
         return;
     }
@@ -845,8 +856,26 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
         if (r < nrows) {
             const int zz = z0 + r / ny, yy = y0 + r % ny;
             const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
-            ms0 = a.cell_start[row + x0];
-            ms1 = a.cell_start[row + x1 + 1];
+            int xa = x0, xb = x1;
+            if (clip.r >= 0.0f) {
+                // distance from the point to the row's slab of cells in y and in z
+                const float gy = fmaxf(fmaxf((float)yy * g.cell - clip.uy,
+                                             clip.uy - (float)(yy + 1) * g.cell), 0.0f);
+                const float gz = fmaxf(fmaxf((float)zz * g.cell - clip.uz,
+                                             clip.uz - (float)(zz + 1) * g.cell), 0.0f);
+                const float rem = clip.r * clip.r - (gy * gy + gz * gz);
+                if (rem >= 0.0f) {
+                    const float xr = sqrtf(rem);
+                    xa = max(x0, (int)fmaxf(floorf((clip.ux - xr) * g.inv), -1.0f));
+                    xb = min(x1, (int)fminf(floorf((clip.ux + xr) * g.inv), 2048.0f));
+                } else {
+                    xb = xa - 1;
+                }
+            }
+            if (xa <= xb) {
+                ms0 = a.cell_start[row + xa];
+                ms1 = a.cell_start[row + xb + 1];
+            }
         }
         const uint32_t len = ms1 - ms0;
         uint32_t incl = len;
@@ -856,13 +885,15 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
         }
         const uint32_t pre = incl - len;  // list position of this lane's row
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        for (uint32_t t0 = 0; t0 < total; t0 += DEPTH * 64) {
+        const uint32_t ns = (total + stride - 1u) / stride;  // list positions 0, stride, 2 stride, ...
+        for (uint32_t s0 = 0; s0 < ns; s0 += DEPTH * 64) {
             uint32_t slot[DEPTH];
             bool v[DEPTH];
             float4 p[DEPTH];
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {
-                const uint32_t t = t0 + j * 64 + lane;
+                const uint32_t sidx = s0 + j * 64 + lane;
+                const uint32_t t = sidx * stride;
                 int lo = 0;  // the last row whose list position is <= t (empty rows share theirs)
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1) {
@@ -870,14 +901,30 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
                     if (pc <= t) lo += step;
                 }
                 slot[j] = __shfl(ms0, lo, 64) + (t - __shfl(pre, lo, 64));
-                v[j] = t < total;
+                v[j] = sidx < ns;
                 p[j] = v[j] ? a.spts[slot[j]] : zero;
             }
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j)
-                if (t0 + j * 64 < total) f(p[j], v[j], slot[j]);
+                if (s0 + j * 64 < ns) f(p[j], v[j], slot[j]);
         }
     }
+}
+
+// Number of points in a box of cells, from the row ranges alone; the same value in every lane.
+__device__ __forceinline__ uint32_t wave_box_count(const CellArgs &a, int x0, int x1, int y0, int y1,
+                                                   int z0, int z1, int lane) {
+    const GridGeom &g = a.g;
+    const int ny = y1 - y0 + 1;
+    const int nrows = ny * (z1 - z0 + 1);
+    uint32_t c = 0;
+    for (int r = lane; r < nrows; r += 64) {
+        const int zz = z0 + r / ny, yy = y0 + r % ny;
+        const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+        c += a.cell_start[row + x1 + 1] - a.cell_start[row + x0];
+    }
+    for (int off = 1; off < 64; off <<= 1) c += __shfl_xor(c, off, 64);
+    return c;
 }
 
 // Retry kernel: ONE WAVE PER QUERY.  The queries that the per-lane kernel could not certify are
@@ -887,6 +934,26 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
 // butterfly over ds_bpermute merges the 64 sorted lists so that all lanes end with the global K
 // smallest.  Identities, when needed, are gathered by a second walk with ballot-compacted appends
 // into a per-wave LDS list, ranked across lanes, and consumed by lane 0.
+// Half-width of the cube a wave tries after the one of half-width R left its query uncertified.
+// tau: the K-th squared distance found inside that cube, +inf when it held fewer than K points.
+// A finite tau bounds the true K-th distance from above, so the cube that reaches sqrt(tau) beyond
+// the query's own cell on every side is certain to certify it: the wave goes straight to that one
+// (a sparse spot of a scan whose cells were sized for its dense parts may need a dozen cells)
+// instead of doubling its way there, and no further than needed.  Without a bound it takes the
+// next entry of the list, and doubles on when the list ends with the whole grid (a cube that has
+// outgrown the grid is the whole grid).  Never beyond the last entry, always beyond R.
+__device__ __forceinline__ int next_half_width(const CellArgs &a, int n_radii, int R, float tau) {
+    const int r_last = a.wave_radii[n_radii - 1];
+    int next = 2 * R;  // past the list (whose last entry, when it stands for the whole grid, is huge)
+    for (int j = n_radii - 1; j >= 0; --j)
+        if (a.wave_radii[j] > R && a.wave_radii[j] < (1 << 20)) next = a.wave_radii[j];
+    if (tau < __builtin_inff()) {
+        const float cells = ceilf(sqrtf(tau) * a.g.inv * 1.0001f) + 1.0f;
+        next = cells < (float)r_last ? (int)cells : r_last;
+    }
+    return min(max(next, R + 1), r_last);
+}
+
 template <int K, bool COLLECT>
 __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut out) {
     constexpr int WAVES = GB_THREADS / 64;
@@ -916,36 +983,36 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         float D[K];
         uint64_t best1 = PCRS_EMPTY_KEY;  // K == 1: key of the nearest point
         bool certified = false;
-        // larger and larger cubes until the K-th distance is certified (the wave is uniform
-        // in the query, so the escalation costs no divergence)
-#pragma unroll 1
-        for (int ri = first_radius; ri < n_radii && !certified; ++ri) {
-            const int R = a.wave_radii[ri];
-            x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
-            y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
-            z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+        const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+        const float allow = g.slack + 2e-6f * amax;  // f32 rounding of cell assignment and offsets
+        // K smallest distances of a box of cells (all of it, every stride-th point of it, or the
+        // part of it inside a ball), merged so that every lane holds them
+        auto search_box = [&](const BallClip &clip, uint32_t stride) {
 #pragma unroll
             for (int i = 0; i < K; ++i) D[i] = __builtin_inff();
             best1 = PCRS_EMPTY_KEY;
-            wave_walk(a, x0, x1, y0, y1, z0, z1, lane, [&](const float4 &p, bool valid, uint32_t) {
-                if (valid) {
-                    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
-                    if constexpr (K == 1) {  // one neighbour: carry its identity along
-                        if (d2 <= D[0]) {
-                            const uint64_t k = make_key(d2, __float_as_uint(p.w));
-                            if (k < best1) {
-                                best1 = k;
-                                D[0] = d2;
+            wave_walk(
+                a, x0, x1, y0, y1, z0, z1, lane,
+                [&](const float4 &p, bool valid, uint32_t) {
+                    if (valid) {
+                        const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+                        if constexpr (K == 1) {  // one neighbour: carry its identity along
+                            if (d2 <= D[0]) {
+                                const uint64_t k = make_key(d2, __float_as_uint(p.w));
+                                if (k < best1) {
+                                    best1 = k;
+                                    D[0] = d2;
+                                }
                             }
-                        }
-                    } else {
+                        } else {
 #pragma unroll
-                        for (int t = K - 1; t > 0; --t)
-                            D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
-                        D[0] = fminf(D[0], d2);
+                            for (int t = K - 1; t > 0; --t)
+                                D[t] = __builtin_amdgcn_fmed3f(d2, D[t - 1], D[t]);
+                            D[0] = fminf(D[0], d2);
+                        }
                     }
-                }
-            });
+                },
+                clip, stride);
             if constexpr (K == 1) {
                 for (int r = 1; r < 64; r <<= 1) {
                     const uint32_t lo = __shfl_xor((uint32_t)best1, r, 64);
@@ -955,46 +1022,93 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
                 }
                 D[0] = key_d2(best1);
             } else {
-            // butterfly merge of the 64 per-lane lists
+                // butterfly merge of the 64 per-lane lists
 #pragma unroll 1
-            for (int r = 1; r < 64; r <<= 1) {
-                float T[K];
+                for (int r = 1; r < 64; r <<= 1) {
+                    float T[K];
 #pragma unroll
-                for (int i = 0; i < K; ++i) T[i] = D[i];
+                    for (int i = 0; i < K; ++i) T[i] = D[i];
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float v = __shfl_xor(T[j], r, 64);
+                    for (int j = 0; j < K; ++j) {
+                        const float v = __shfl_xor(T[j], r, 64);
 #pragma unroll
-                    for (int t = K - 1; t > 0; --t)
-                        D[t] = __builtin_amdgcn_fmed3f(v, D[t - 1], D[t]);
-                    D[0] = fminf(D[0], v);
+                        for (int t = K - 1; t > 0; --t)
+                            D[t] = __builtin_amdgcn_fmed3f(v, D[t - 1], D[t]);
+                        D[0] = fminf(D[0], v);
+                    }
                 }
             }
-            }
-            const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
-                               (z0 == 0) && (z1 == g.nz - 1);
-            certified = whole;
-            float tau_cert = __builtin_inff();
+        };
+        auto kth = [&](uint32_t kk) {  // D[kk - 1]
+            float v = __builtin_inff();
 #pragma unroll
             for (int i = 0; i < K; ++i)
-                if ((uint32_t)i == a.kcert - 1) tau_cert = D[i];
-            if (!whole) {
-                float margin = __builtin_inff();
-                const float u[3] = {ux, uy, uz};
-                const int c[3] = {cx, cy, cz};
-                const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    if (c[ax] - R > 0)
-                        margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                    if (c[ax] + R < n[ax] - 1)
-                        margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-                }
-                const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
-                const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
-                certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f) ||
-                                           (K == 1 && a.useful_d2 < (m * m) * (1.0f - 2e-6f)));
+                if ((uint32_t)i == kk - 1) v = D[i];
+            return v;
+        };
+        // Larger and larger cubes until one holds enough points (counted from the row ranges
+        // alone: no point is read, nothing merged).  That cube is searched — every stride-th point
+        // of it when it is large — and what it gives is either certified by the distance to the
+        // cube's faces or an upper bound of the K-th distance; the ball of that radius is then
+        // searched exactly, whatever cube it needs.  A stray point above a dense surface costs the
+        // few rows under it instead of the square of surface that a cube around it would cover.
+        // (The wave is uniform in the query, so none of this diverges.)
+        const int r_last = a.wave_radii[n_radii - 1];
+        int R = a.wave_radii[first_radius];
+#pragma unroll 1
+        for (;;) {
+            x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+            y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+            z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+            const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
+                               (z0 == 0) && (z1 == g.nz - 1);
+            const uint32_t n_box = whole ? a.nvalid : wave_box_count(a, x0, x1, y0, y1, z0, z1, lane);
+            if (!whole && n_box < a.kcert) {
+                if (R >= r_last) break;
+                R = next_half_width(a, n_radii, R, __builtin_inff());
+                continue;
             }
+            const uint32_t stride = n_box > 8192u ? n_box / 2048u : 1u;
+            search_box(BallClip{0.0f, 0.0f, 0.0f, -1.0f}, stride);
+            const float tau_cert = kth(a.kcert);
+            if (stride == 1u) {
+                certified = whole;
+                if (!whole) {
+                    float margin = __builtin_inff();
+                    const float u[3] = {ux, uy, uz};
+                    const int c[3] = {cx, cy, cz};
+                    const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (c[ax] - R > 0)
+                            margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                        if (c[ax] + R < n[ax] - 1)
+                            margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+                    }
+                    const float m = (margin - allow) * (1.0f - 2e-6f);
+                    certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f) ||
+                                               (K == 1 && a.useful_d2 < (m * m) * (1.0f - 2e-6f)));
+                }
+                if (certified) break;
+            }
+            // at least kcert points lie within `bound` of the query (for one neighbour: or nothing
+            // beyond it is of use), so the kcert nearest are inside the ball of that radius
+            const float bound = K == 1 ? fminf(tau_cert, a.useful_d2) : tau_cert;
+            if (!(bound < __builtin_inff())) {
+                if (R >= r_last) break;
+                R = next_half_width(a, n_radii, R, bound);
+                continue;
+            }
+            const float rb = sqrtf(bound) * (1.0f + 4e-6f) + 2.0f * allow;
+            const float cells = ceilf(rb * g.inv);
+            if (!(cells <= (float)r_last)) break;  // beyond what this launch may search
+            R = max((int)cells, 1);
+            x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+            y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+            z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+            search_box(BallClip{ux, uy, uz, rb}, 1u);
+            certified = true;
+            break;
         }
         bool failed = !certified;
 
@@ -1011,15 +1125,23 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             for (int i = 0; i < K; ++i)
                 if ((uint32_t)i == a.kcollect - 1) tau = D[i];
             uint32_t base = 0;
-            wave_walk(a, x0, x1, y0, y1, z0, z1, lane, [&](const float4 &p, bool valid, uint32_t s) {
-                const bool hit = valid && sqdist(qx, qy, qz, p.x, p.y, p.z) <= tau;
-                const unsigned long long mask = __ballot(hit);
-                if (hit) {
-                    const uint32_t at = base + (uint32_t)__popcll(mask & lt_mask);
-                    if (at < 64u) wl_slot[w][at] = s;
-                }
-                base += (uint32_t)__popcll(mask);
-            });
+            // every hit lies in the ball of the collected distance: only its rows are walked
+            const BallClip ball = {ux, uy, uz,
+                                   tau < __builtin_inff()
+                                       ? sqrtf(tau) * (1.0f + 4e-6f) + 2.0f * allow
+                                       : -1.0f};
+            wave_walk(
+                a, x0, x1, y0, y1, z0, z1, lane,
+                [&](const float4 &p, bool valid, uint32_t s) {
+                    const bool hit = valid && sqdist(qx, qy, qz, p.x, p.y, p.z) <= tau;
+                    const unsigned long long mask = __ballot(hit);
+                    if (hit) {
+                        const uint32_t at = base + (uint32_t)__popcll(mask & lt_mask);
+                        if (at < 64u) wl_slot[w][at] = s;
+                    }
+                    base += (uint32_t)__popcll(mask);
+                },
+                ball, 1u);
             if (base > 64u) {
                 failed = true;  // more ties at the K-th distance than the list holds
             } else {
@@ -1159,9 +1281,10 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
     uint64_t best = PCRS_EMPTY_KEY;
     float best_d2 = __builtin_inff();
     bool certified = false;
+    const int r_last = a.wave_radii[a.n_radii - 1];
+    int R = a.wave_radii[(entry & PCRS_HEAVY_FLAG) ? 0 : 1];
 #pragma unroll 1
-    for (int ri = (entry & PCRS_HEAVY_FLAG) ? 0 : 1; ri < a.n_radii && !certified; ++ri) {
-        const int R = a.wave_radii[ri];
+    for (;;) {
         const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
         const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
@@ -1204,6 +1327,8 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
             certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
                                        a.useful_d2 < (m * m) * (1.0f - 2e-6f));
         }
+        if (certified || R >= r_last) break;
+        R = next_half_width(a, a.n_radii, R, fminf(best_d2, a.useful_d2));
     }
     if (lane != 0) return;
     if (!certified) {

@@ -347,6 +347,41 @@ def test_obstacle_pipeline_matches_oracle(hip, oracle):
         assert np.array_equal(a, b)
 
 
+def test_knn_strays_over_dense_surface(hip, oracle):
+    """Stray points high above (and far beside) a dense plane: their neighbours lie many cells
+    away, in a small patch of the plane.  The retry stage bounds their K-th distance from a sample
+    of a large cube and then searches only the ball of that radius; identities, order and distances
+    must still be those of the exhaustive search, as lists (k = 21, 8) and through the consumers."""
+    rng = np.random.default_rng(77)
+    n_plane, n_stray = 60000, 400
+    plane = np.stack([rng.uniform(-20, 20, n_plane), rng.uniform(-20, 20, n_plane),
+                      rng.uniform(-0.05, 0.05, n_plane)], 1)
+    stray = np.stack([rng.uniform(-30, 30, n_stray), rng.uniform(-30, 30, n_stray),
+                      rng.uniform(-6, 14, n_stray)], 1)
+    far = np.array([[150.0, -90.0, 40.0], [-200.0, 10.0, 0.0], [0.0, 0.0, 300.0]])
+    pts = np.concatenate([plane, stray, far]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    x, y, z = (np.ascontiguousarray(pts[:, a]) for a in range(3))
+    sparse = np.nonzero(np.abs(z) > 0.06)[0]
+    for k in (21, 8):
+        ix = hip.Index(x, y, z, k_hint=k)
+        idx, dist, cnt = ix.knn(x[sparse], y[sparse], z[sparse], k)
+        st = ix.last_stats()
+        assert st["grid_ring"] > 100 and st["brute"] == 0  # the strays do take the retry stage
+        ridx, rdist, _, rcnt = oracle.knn(x, y, z, x[sparse], y[sparse], z[sparse], k, algo=1)
+        assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
+        assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+        ix.close()
+    keep, n_keep, thr, mean = hip.sor(x, y, z, 20, 2.0)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, 20, 2.0, algo=1)
+    assert np.array_equal(mean.view(np.uint32), rmean.view(np.uint32))
+    assert np.array_equal(keep, rkeep) and n_keep == rn and np.float32(thr) == np.float32(rthr)
+    nrm = hip.normals(x, y, z, 16)
+    rnrm = oracle.normals(x, y, z, 16, algo=1)
+    ok = normals_close(nrm, rnrm, 1e-5)
+    assert ok.mean() > 0.9999 and ok[sparse].mean() > 0.99, (ok.mean(), ok[sparse].mean())
+
+
 def test_apply_transform_bit_exact(hip, oracle):
     x, y, z = gen.uniform_cloud(10000, 4, -50, 50)
     R = gen.rot_z(0.3)

@@ -11,6 +11,8 @@
 // reference's exactly.
 #include "knn_common.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace pcrs {
@@ -167,12 +169,37 @@ __global__ __launch_bounds__(256) void cluster_union_wave_kernel(
     const float ax = x[a], ay = y[a], az = z[a];
     const long long cx = ux[cell], cy = uy[cell], cz = uz[cell];
     uint32_t root = a;  // what this lane last saw as the root of a (see cluster_union_kernel)
+    // The up to 64 neighbours of a step are joined to a by the wave as a whole: all lanes calling
+    // uf_union for the same point would queue up on the one root they all try to move (one
+    // compare-and-swap wins per round, the others start over).  Here every lane finds the root of
+    // its own neighbour, the smallest root of the step (a's included) is agreed on by shuffles, and
+    // each distinct larger root is hung under it — different addresses, one round nearly always.
     auto join_range = [&](uint32_t from, uint32_t to) {
-        for (uint32_t j = from + lane; j < to; j += 64u) {
-            const uint32_t b = order[j];
-            const float dx = ax - x[b], dy = ay - y[b], dz = az - z[b];
-            if ((dx * dx + dy * dy) + dz * dz <= r2 && b != root && parent[b] != root)
-                root = uf_union(parent, a, b);  // :151-153
+        for (uint32_t j0 = from; j0 < to; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            uint32_t b = a;
+            bool hit = false;
+            if (j < to) {
+                b = order[j];
+                const float dx = ax - x[b], dy = ay - y[b], dz = az - z[b];
+                hit = (dx * dx + dy * dy) + dz * dz <= r2 && b != root && parent[b] != root;  // :151-153
+            }
+            while (__ballot(hit)) {
+                const uint32_t ra = uf_find(parent, a);  // the same in every lane
+                const uint32_t rb = hit ? uf_find(parent, b) : ra;
+                uint32_t m = rb < ra ? rb : ra;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_xor(m, off, 64);
+                    m = o < m ? o : m;
+                }
+                // a larger root goes under the smallest one (indices only ever point downwards);
+                // a lost race — the root was moved by someone else meanwhile — shows up as a
+                // different root in the next round
+                if (hit && rb != m) atomicCAS(parent + rb, rb, m);
+                if (lane == 0u && ra != m) atomicCAS(parent + ra, ra, m);
+                root = m;
+                hit = hit && rb != ra;  // joined already when the two roots were one
+            }
         }
     };
     join_range(i + 1, first[cell + 1]);  // own cell: the points after this one (:148)
@@ -308,7 +335,13 @@ int pcrs_launch_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y,
                                cs.flag.as<uint8_t>(), cs.cell_id.as<uint32_t>(), cs.order, nv,
                                cs.k[0].as<int>(), cs.k[1].as<int>(), cs.k[2].as<int>(),
                                first.as<uint32_t>(), u[0].as<int>(), u[1].as<int>(), u[2].as<int>());
-            if (nv <= 65536u)  // few points: a wave each
+            static const uint32_t wave_max = [] {  // experiments only: PCRS_CLUSTER_WAVE_MAX
+                const char *e = getenv("PCRS_CLUSTER_WAVE_MAX");
+                return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u;
+            }();
+            // few points: a wave each (measured on crowded blobs: 0.36 against 0.54 ms at 5 K
+            // points, even at 20 K, 2.4 against 1.0 ms at 60 K — more waves, more contention)
+            if (nv <= wave_max)
                 hipLaunchKernelGGL(cluster_union_wave_kernel, dim3((nv + 3) / 4), dim3(256), 0,
                                    ctx->stream, x, y, z, cs.flag.as<uint8_t>(),
                                    cs.cell_id.as<uint32_t>(), cs.order, nv, first.as<uint32_t>(),

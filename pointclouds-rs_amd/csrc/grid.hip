@@ -470,7 +470,7 @@ struct CellArgs {
     const uint32_t *qlist;
     const uint32_t *qcount;
     int R;                  // cube half-width in cells (per-lane kernels)
-    int wave_radii[5];      // cube half-widths the wave-per-query kernel tries in turn; entry 0
+    int wave_radii[5];      // cube half-widths the wave-per-query kernel starts from; entry 0
                             // is only for queries flagged PCRS_HEAVY_FLAG in the list
     int n_radii;            // entries of wave_radii in use
     float useful_d2;        // 1-NN only: neighbours beyond this squared distance are of no use
@@ -824,6 +824,24 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
 struct BallClip {
     float ux, uy, uz, r;
 };
+// cells [xa, xb] of the row (yy, zz) of a box spanning x0 .. x1 that the clip leaves (xa > xb: none)
+__device__ __forceinline__ void clipped_row(const GridGeom &g, const BallClip &clip, int x0, int x1,
+                                            int yy, int zz, int *xa, int *xb) {
+    *xa = x0;
+    *xb = x1;
+    if (clip.r < 0.0f) return;
+    // distance from the point to the row's slab of cells in y and in z
+    const float gy = fmaxf(fmaxf((float)yy * g.cell - clip.uy, clip.uy - (float)(yy + 1) * g.cell), 0.0f);
+    const float gz = fmaxf(fmaxf((float)zz * g.cell - clip.uz, clip.uz - (float)(zz + 1) * g.cell), 0.0f);
+    const float rem = clip.r * clip.r - (gy * gy + gz * gz);
+    if (rem >= 0.0f) {
+        const float xr = sqrtf(rem);
+        *xa = max(x0, (int)fmaxf(floorf((clip.ux - xr) * g.inv), -1.0f));
+        *xb = min(x1, (int)fminf(floorf((clip.ux + xr) * g.inv), 2048.0f));
+    } else {
+        *xb = x0 - 1;
+    }
+}
 template <int DEPTH_ALL = 8, int DEPTH = 4, class F>
 __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int y0, int y1, int z0,
                                           int z1, int lane, F f,
@@ -856,22 +874,8 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
         if (r < nrows) {
             const int zz = z0 + r / ny, yy = y0 + r % ny;
             const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
-            int xa = x0, xb = x1;
-            if (clip.r >= 0.0f) {
-                // distance from the point to the row's slab of cells in y and in z
-                const float gy = fmaxf(fmaxf((float)yy * g.cell - clip.uy,
-                                             clip.uy - (float)(yy + 1) * g.cell), 0.0f);
-                const float gz = fmaxf(fmaxf((float)zz * g.cell - clip.uz,
-                                             clip.uz - (float)(zz + 1) * g.cell), 0.0f);
-                const float rem = clip.r * clip.r - (gy * gy + gz * gz);
-                if (rem >= 0.0f) {
-                    const float xr = sqrtf(rem);
-                    xa = max(x0, (int)fmaxf(floorf((clip.ux - xr) * g.inv), -1.0f));
-                    xb = min(x1, (int)fminf(floorf((clip.ux + xr) * g.inv), 2048.0f));
-                } else {
-                    xb = xa - 1;
-                }
-            }
+            int xa, xb;
+            clipped_row(g, clip, x0, x1, yy, zz, &xa, &xb);
             if (xa <= xb) {
                 ms0 = a.cell_start[row + xa];
                 ms1 = a.cell_start[row + xb + 1];
@@ -911,9 +915,11 @@ __device__ __forceinline__ void wave_walk(const CellArgs &a, int x0, int x1, int
     }
 }
 
-// Number of points in a box of cells, from the row ranges alone; the same value in every lane.
+// Number of points in a box of cells (in the part of it that the clip leaves), from the row ranges
+// alone; the same value in every lane.
 __device__ __forceinline__ uint32_t wave_box_count(const CellArgs &a, int x0, int x1, int y0, int y1,
-                                                   int z0, int z1, int lane) {
+                                                   int z0, int z1, int lane,
+                                                   BallClip clip = BallClip{0.0f, 0.0f, 0.0f, -1.0f}) {
     const GridGeom &g = a.g;
     const int ny = y1 - y0 + 1;
     const int nrows = ny * (z1 - z0 + 1);
@@ -921,19 +927,14 @@ __device__ __forceinline__ uint32_t wave_box_count(const CellArgs &a, int x0, in
     for (int r = lane; r < nrows; r += 64) {
         const int zz = z0 + r / ny, yy = y0 + r % ny;
         const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
-        c += a.cell_start[row + x1 + 1] - a.cell_start[row + x0];
+        int xa, xb;
+        clipped_row(g, clip, x0, x1, yy, zz, &xa, &xb);
+        if (xa <= xb) c += a.cell_start[row + xb + 1] - a.cell_start[row + xa];
     }
     for (int off = 1; off < 64; off <<= 1) c += __shfl_xor(c, off, 64);
     return c;
 }
 
-// Retry kernel: ONE WAVE PER QUERY.  The queries that the per-lane kernel could not certify are
-// few and scattered, so a lane-per-query retry would be a handful of long serial walks.  Here the
-// 64 lanes of a wave share one query: they stride over each row of the (2R+1)^3 cube (coalesced
-// float4 loads), every lane keeps the K smallest distances of its share, and a 6-step xor
-// butterfly over ds_bpermute merges the 64 sorted lists so that all lanes end with the global K
-// smallest.  Identities, when needed, are gathered by a second walk with ballot-compacted appends
-// into a per-wave LDS list, ranked across lanes, and consumed by lane 0.
 // Half-width of the cube a wave tries after the one of half-width R left its query uncertified.
 // tau: the K-th squared distance found inside that cube, +inf when it held fewer than K points.
 // A finite tau bounds the true K-th distance from above, so the cube that reaches sqrt(tau) beyond
@@ -954,6 +955,13 @@ __device__ __forceinline__ int next_half_width(const CellArgs &a, int n_radii, i
     return min(max(next, R + 1), r_last);
 }
 
+// Retry kernel: ONE WAVE PER QUERY.  The queries that the per-lane kernel could not certify are
+// few and scattered, so a lane-per-query retry would be a handful of long serial walks.  Here the
+// 64 lanes of a wave share one query: they stride over each row of the (2R+1)^3 cube (coalesced
+// float4 loads), every lane keeps the K smallest distances of its share, and a 6-step xor
+// butterfly over ds_bpermute merges the 64 sorted lists so that all lanes end with the global K
+// smallest.  Identities, when needed, are gathered by a second walk with ballot-compacted appends
+// into a per-wave LDS list, ranked across lanes, and consumed by lane 0.
 template <int K, bool COLLECT>
 __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut out) {
     constexpr int WAVES = GB_THREADS / 64;
@@ -1047,14 +1055,21 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             return v;
         };
         // Larger and larger cubes until one holds enough points (counted from the row ranges
-        // alone: no point is read, nothing merged).  That cube is searched — every stride-th point
-        // of it when it is large — and what it gives is either certified by the distance to the
-        // cube's faces or an upper bound of the K-th distance; the ball of that radius is then
-        // searched exactly, whatever cube it needs.  A stray point above a dense surface costs the
-        // few rows under it instead of the square of surface that a cube around it would cover.
+        // alone: no point is read, nothing merged).  That cube is searched, and what it gives is
+        // either certified by the distance to the cube's faces or an upper bound of the K-th
+        // distance; the ball of that radius then holds the answer, whatever cube it needs, and only
+        // the cells that reach into it are searched.  A region of more than 8192 points is sampled
+        // first (every n-th point of its list): the K-th distance of the sample is a bound too, and
+        // its ball is a much smaller region.  A stray point above a dense surface thus costs a
+        // sample and the few rows under it instead of the square of surface that a cube around it
+        // would cover, and a stray far from a large cloud a few samples instead of the cloud.
         // (The wave is uniform in the query, so none of this diverges.)
         const int r_last = a.wave_radii[n_radii - 1];
         int R = a.wave_radii[first_radius];
+        BallClip clip = {ux, uy, uz, -1.0f};  // the region is the box, cut to this ball once r >= 0
+        uint32_t n_region = 0;
+        bool counted = false;
+        float bound = __builtin_inff();  // smallest upper bound of the kcert-th distance so far
 #pragma unroll 1
         for (;;) {
             x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
@@ -1062,18 +1077,25 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
             const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
                                (z0 == 0) && (z1 == g.nz - 1);
-            const uint32_t n_box = whole ? a.nvalid : wave_box_count(a, x0, x1, y0, y1, z0, z1, lane);
-            if (!whole && n_box < a.kcert) {
+            if (!counted)
+                n_region = (whole && clip.r < 0.0f) ? a.nvalid
+                                                    : wave_box_count(a, x0, x1, y0, y1, z0, z1, lane, clip);
+            counted = false;
+            if (clip.r < 0.0f && !whole && n_region < a.kcert) {  // too few points to certify any
                 if (R >= r_last) break;
                 R = next_half_width(a, n_radii, R, __builtin_inff());
                 continue;
             }
-            const uint32_t stride = n_box > 8192u ? n_box / 2048u : 1u;
-            search_box(BallClip{0.0f, 0.0f, 0.0f, -1.0f}, stride);
+            const uint32_t stride = n_region > 8192u ? n_region / 2048u : 1u;
+            search_box(clip, stride);
             const float tau_cert = kth(a.kcert);
             if (stride == 1u) {
-                certified = whole;
-                if (!whole) {
+                // every point of the region was seen: a ball around a bound holds the answer (the
+                // comparison can only fail if the ball missed a cell it should have had: such a
+                // query is left to the brute-force stage rather than answered wrongly)
+                certified = whole || (clip.r >= 0.0f && (K == 1 || tau_cert <= bound));
+                if (!certified && clip.r >= 0.0f) break;
+                if (!certified) {
                     float margin = __builtin_inff();
                     const float u[3] = {ux, uy, uz};
                     const int c[3] = {cx, cy, cz};
@@ -1093,7 +1115,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             }
             // at least kcert points lie within `bound` of the query (for one neighbour: or nothing
             // beyond it is of use), so the kcert nearest are inside the ball of that radius
-            const float bound = K == 1 ? fminf(tau_cert, a.useful_d2) : tau_cert;
+            bound = fminf(bound, K == 1 ? fminf(tau_cert, a.useful_d2) : tau_cert);
             if (!(bound < __builtin_inff())) {
                 if (R >= r_last) break;
                 R = next_half_width(a, n_radii, R, bound);
@@ -1103,12 +1125,21 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             const float cells = ceilf(rb * g.inv);
             if (!(cells <= (float)r_last)) break;  // beyond what this launch may search
             R = max((int)cells, 1);
-            x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
-            y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
-            z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
-            search_box(BallClip{ux, uy, uz, rb}, 1u);
-            certified = true;
-            break;
+            clip.r = rb;
+            // a sample whose ball is hardly smaller than the region it came from (points at equal
+            // distances all around) is not tried twice: the region is then searched as it is
+            const int bx0 = max(cx - R, 0), bx1 = min(cx + R, g.nx - 1);
+            const int by0 = max(cy - R, 0), by1 = min(cy + R, g.ny - 1);
+            const int bz0 = max(cz - R, 0), bz1 = min(cz + R, g.nz - 1);
+            const uint32_t n_ball = wave_box_count(a, bx0, bx1, by0, by1, bz0, bz1, lane, clip);
+            counted = true;
+            if (stride > 1u && n_ball > n_region / 2u) {
+                x0 = bx0, x1 = bx1, y0 = by0, y1 = by1, z0 = bz0, z1 = bz1;
+                search_box(clip, 1u);
+                certified = true;
+                break;
+            }
+            n_region = n_ball;
         }
         bool failed = !certified;
 
@@ -2292,18 +2323,20 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         a.wy = q.wy;
         a.wz = q.wz;
     }
-    // one launch tries the cube half-widths 2, 4, 8 in turn for each failed query
+    // one launch grows the cube of each failed query from these half-widths (next_half_width)
     a.wave_radii[0] = 1;
     a.wave_radii[1] = 2;
     a.wave_radii[2] = 4;
     a.wave_radii[3] = 8;
     a.n_radii = 4;
-    // Clouds of up to 4 M points end with the whole grid as the last "cube": for the queries that
-    // are left (points far from the cloud) one wave scanning every point costs far less than the
-    // tiled brute-force kernel, where a single lane would work through the whole cloud.  1-NN
-    // searches then need no brute-force launch at all; longer lists keep it for tie overflows and
-    // for floods of stray queries (all_gate).
-    const bool wave_all = ix->nvalid <= (size_t)4 << 20;
+    // The list ends with the whole grid as the last "cube": for the queries that are left (points
+    // far from the cloud) a wave costs far less than the tiled brute-force kernel, where a single
+    // lane would work through the whole cloud.  The k-NN retry samples large regions and then
+    // searches a ball, so the size of the cloud does not matter to it; the 1-NN retry scans the
+    // whole grid point by point and gets it for clouds of up to 4 M points only.  1-NN searches
+    // then need no brute-force launch at all; longer lists keep it for tie overflows and for
+    // floods of stray queries (all_gate).
+    const bool wave_all = !nn_only || ix->nvalid <= (size_t)4 << 20;
     const bool wave_does_all = nn_only && wave_all;  // one neighbour: no list can overflow
     a.all_gate = 0xFFFFFFFFu;
     if (wave_all) {

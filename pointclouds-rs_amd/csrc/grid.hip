@@ -1123,8 +1123,12 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             }
             const float rb = sqrtf(bound) * (1.0f + 4e-6f) + 2.0f * allow;
             const float cells = ceilf(rb * g.inv);
-            if (!(cells <= (float)r_last)) break;  // beyond what this launch may search
-            R = max((int)cells, 1);
+            if (cells <= (float)r_last) {
+                R = max((int)cells, 1);
+            } else {
+                if (r_last < (1 << 20)) break;  // beyond what this launch may search
+                R = r_last;                     // the whole grid, cut to the ball
+            }
             clip.r = rb;
             // a sample whose ball is hardly smaller than the region it came from (points at equal
             // distances all around) is not tried twice: the region is then searched as it is

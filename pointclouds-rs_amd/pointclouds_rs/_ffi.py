@@ -6,6 +6,7 @@ context is created, the call raises.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import os
 import threading
 
@@ -185,6 +186,9 @@ class Context:
             self.handle = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: the process frees it all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -6,6 +6,7 @@ goes through libpcrs_hip.so; nothing here computes on the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -61,6 +62,9 @@ class Index:
             self.handle = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: the process frees it all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -289,6 +293,9 @@ class Icp:
             self.handle = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: the process frees it all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -1086,9 +1086,16 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
                 R = next_half_width(a, n_radii, R, __builtin_inff());
                 continue;
             }
-            const uint32_t stride = n_region > 8192u ? n_region / 2048u : 1u;
+            uint32_t stride = n_region > 8192u ? n_region / 2048u : 1u;
             search_box(clip, stride);
-            const float tau_cert = kth(a.kcert);
+            float tau_cert = kth(a.kcert);
+            if (stride > 1u && !(fminf(bound, tau_cert) < __builtin_inff())) {
+                // a sample without a finite distance (coordinates whose squares overflow) bounds
+                // nothing: the region is searched as it is
+                stride = 1u;
+                search_box(clip, 1u);
+                tau_cert = kth(a.kcert);
+            }
             if (stride == 1u) {
                 // every point of the region was seen: a ball around a bound holds the answer (the
                 // comparison can only fail if the ball missed a cell it should have had: such a
@@ -1300,11 +1307,11 @@ __global__ __launch_bounds__(GB_THREADS) void owned_write_kernel(const float4 *s
         if (f & (1u << i)) list[at++] = first + i;
 }
 
-// 1-NN retry of ONE query by a whole wave (the K = 1 case of knn_wave_kernel as a function): cubes
-// of half-width a.wave_radii[...] in turn until the nearest point is certified, the whole grid
-// last where the launch allows it.  Lane 0 stores the answer; a query that stays uncertified goes
-// to a.fail_list for the brute-force stage.  entry: query index, PCRS_HEAVY_FLAG set when the
-// 27-cell cube itself is still to be searched.
+// 1-NN retry of ONE query by a whole wave (the K = 1 case of knn_wave_kernel as a function, see
+// there): larger and larger cubes until one holds a point, a search of that cube (of a sample of
+// it when it is large), then the ball of the distance found.  Lane 0 stores the answer; a query
+// that stays uncertified goes to a.fail_list for the brute-force stage.  entry: query index,
+// PCRS_HEAVY_FLAG set when the 27-cell cube itself is still to be searched.
 __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &out, uint32_t entry,
                                                float qx, float qy, float qz, int lane) {
     const GridGeom &g = a.g;
@@ -1313,30 +1320,29 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
     const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
     const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
     const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+    const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+    const float allow = g.slack + 2e-6f * amax;
     uint64_t best = PCRS_EMPTY_KEY;
     float best_d2 = __builtin_inff();
-    bool certified = false;
-    const int r_last = a.wave_radii[a.n_radii - 1];
-    int R = a.wave_radii[(entry & PCRS_HEAVY_FLAG) ? 0 : 1];
-#pragma unroll 1
-    for (;;) {
-        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
-        const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
-        const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
+    auto search_box = [&](const BallClip &clip, uint32_t stride) {
         best = PCRS_EMPTY_KEY;
         best_d2 = __builtin_inff();
-        wave_walk<4, 2>(a, x0, x1, y0, y1, z0, z1, lane, [&](const float4 &p, bool valid, uint32_t) {
-            if (valid) {
-                const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
-                if (d2 <= best_d2) {
-                    const uint64_t k = make_key(d2, __float_as_uint(p.w));
-                    if (k < best) {
-                        best = k;
-                        best_d2 = d2;
+        wave_walk<4, 2>(
+            a, x0, x1, y0, y1, z0, z1, lane,
+            [&](const float4 &p, bool valid, uint32_t) {
+                if (valid) {
+                    const float d2 = sqdist(qx, qy, qz, p.x, p.y, p.z);
+                    if (d2 <= best_d2) {
+                        const uint64_t k = make_key(d2, __float_as_uint(p.w));
+                        if (k < best) {
+                            best = k;
+                            best_d2 = d2;
+                        }
                     }
                 }
-            }
-        });
+            },
+            clip, stride);
         for (int r = 1; r < 64; r <<= 1) {
             const uint32_t lo = __shfl_xor((uint32_t)best, r, 64);
             const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), r, 64);
@@ -1344,9 +1350,27 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
             if (other < best) best = other;
         }
         best_d2 = key_d2(best);
-        certified = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) && (z0 == 0) &&
-                    (z1 == g.nz - 1);
-        if (!certified) {
+    };
+    bool certified = false;
+    const int r_last = a.wave_radii[a.n_radii - 1];
+    int R = a.wave_radii[(entry & PCRS_HEAVY_FLAG) ? 0 : 1];
+    BallClip clip = {ux, uy, uz, -1.0f};
+    uint32_t n_region = 0;
+    bool counted = false;
+    float bound = __builtin_inff();  // nothing farther than this can be the answer
+#pragma unroll 1
+    for (;;) {
+        x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+        y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+        z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+        const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
+                           (z0 == 0) && (z1 == g.nz - 1);
+        if (!counted)
+            n_region = (whole && clip.r < 0.0f) ? a.nvalid
+                                                : wave_box_count(a, x0, x1, y0, y1, z0, z1, lane, clip);
+        counted = false;
+        if (clip.r < 0.0f && !whole && n_region == 0u) {  // an empty cube
+            // ... which still settles the query when nothing outside it can be of use
             float margin = __builtin_inff();
             const float u[3] = {ux, uy, uz};
             const int c[3] = {cx, cy, cz};
@@ -1357,13 +1381,71 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
                 if (c[ax] + R < n[ax] - 1)
                     margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
             }
-            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
-            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
-            certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
-                                       a.useful_d2 < (m * m) * (1.0f - 2e-6f));
+            const float m = (margin - allow) * (1.0f - 2e-6f);
+            if (m > 0.0f && a.useful_d2 < (m * m) * (1.0f - 2e-6f)) {
+                best = PCRS_EMPTY_KEY;
+                best_d2 = __builtin_inff();
+                certified = true;
+                break;
+            }
+            if (R >= r_last) break;
+            R = next_half_width(a, a.n_radii, R, a.useful_d2);
+            continue;
         }
-        if (certified || R >= r_last) break;
-        R = next_half_width(a, a.n_radii, R, fminf(best_d2, a.useful_d2));
+        uint32_t stride = n_region > 8192u ? n_region / 2048u : 1u;
+        search_box(clip, stride);
+        if (stride > 1u && !(fminf(bound, fminf(best_d2, a.useful_d2)) < __builtin_inff())) {
+            // a sample without a finite distance (coordinates whose squares overflow) bounds
+            // nothing: the region is searched as it is
+            stride = 1u;
+            search_box(clip, 1u);
+        }
+        if (stride == 1u) {
+            certified = whole || clip.r >= 0.0f;
+            if (!certified) {
+                float margin = __builtin_inff();
+                const float u[3] = {ux, uy, uz};
+                const int c[3] = {cx, cy, cz};
+                const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                    if (c[ax] + R < n[ax] - 1)
+                        margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+                }
+                const float m = (margin - allow) * (1.0f - 2e-6f);
+                certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
+                                           a.useful_d2 < (m * m) * (1.0f - 2e-6f));
+            }
+            if (certified) break;
+        }
+        bound = fminf(bound, fminf(best_d2, a.useful_d2));
+        if (!(bound < __builtin_inff())) {
+            if (R >= r_last) break;
+            R = next_half_width(a, a.n_radii, R, bound);
+            continue;
+        }
+        const float rb = sqrtf(bound) * (1.0f + 4e-6f) + 2.0f * allow;
+        const float cells = ceilf(rb * g.inv);
+        if (cells <= (float)r_last) {
+            R = max((int)cells, 1);
+        } else {
+            if (r_last < (1 << 20)) break;  // beyond what this launch may search
+            R = r_last;                     // the whole grid, cut to the ball
+        }
+        clip.r = rb;
+        const int bx0 = max(cx - R, 0), bx1 = min(cx + R, g.nx - 1);
+        const int by0 = max(cy - R, 0), by1 = min(cy + R, g.ny - 1);
+        const int bz0 = max(cz - R, 0), bz1 = min(cz + R, g.nz - 1);
+        const uint32_t n_ball = wave_box_count(a, bx0, bx1, by0, by1, bz0, bz1, lane, clip);
+        counted = true;
+        if (stride > 1u && n_ball > n_region / 2u) {  // a sample that did not narrow the region
+            x0 = bx0, x1 = bx1, y0 = by0, y1 = by1, z0 = bz0, z1 = bz1;
+            search_box(clip, 1u);
+            certified = true;
+            break;
+        }
+        n_region = n_ball;
     }
     if (lane != 0) return;
     if (!certified) {
@@ -1383,7 +1465,8 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
 // list (coalesced 128-byte reads), which makes eight times the waves and an eighth of the chain.
 constexpr int NN_SUB = 8;
 
-__global__ __launch_bounds__(GB_THREADS) void nn_cell_kernel(CellArgs a, KnnOut out) {
+__global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
+void nn_cell_kernel(CellArgs a, KnnOut out) {
     if (a.zero_me && blockIdx.x == 0 && threadIdx.x < 16) a.zero_me[threadIdx.x] = 0u;
     if (a.skip && *a.skip) return;
     uint32_t total = a.nq;
@@ -2335,19 +2418,14 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.n_radii = 4;
     // The list ends with the whole grid as the last "cube": for the queries that are left (points
     // far from the cloud) a wave costs far less than the tiled brute-force kernel, where a single
-    // lane would work through the whole cloud.  The k-NN retry samples large regions and then
-    // searches a ball, so the size of the cloud does not matter to it; the 1-NN retry scans the
-    // whole grid point by point and gets it for clouds of up to 4 M points only.  1-NN searches
-    // then need no brute-force launch at all; longer lists keep it for tie overflows and for
-    // floods of stray queries (all_gate).
-    const bool wave_all = !nn_only || ix->nvalid <= (size_t)4 << 20;
-    const bool wave_does_all = nn_only && wave_all;  // one neighbour: no list can overflow
-    a.all_gate = 0xFFFFFFFFu;
-    if (wave_all) {
-        a.wave_radii[4] = 1 << 20;
-        a.n_radii = 5;
-        if (!nn_only) a.all_gate = 65536u;
-    }
+    // lane would work through the whole cloud.  The retries sample large regions and then search
+    // a ball, so the size of the cloud does not matter to them.  1-NN searches need no
+    // brute-force launch at all; longer lists keep it for tie overflows and for floods of stray
+    // queries (all_gate).
+    const bool wave_does_all = nn_only;  // one neighbour: no list can overflow
+    a.wave_radii[4] = 1 << 20;
+    a.n_radii = 5;
+    a.all_gate = nn_only ? 0xFFFFFFFFu : 65536u;
     if (nn_only) {
         // the 1-NN kernel retries in place (a wave per failed query, right behind the wave's own
         // first stage): what it still cannot certify goes straight to the brute-force list

@@ -793,9 +793,10 @@ def test_search_stage_statistics():
 
 
 def test_correspondences_bounded_on_a_target_beyond_the_whole_grid_scan(hip, oracle):
-    """Targets above 4 M points have no whole-grid scan by one wave as their last search stage:
-    what the cubes leave goes to the tiled brute-force kernel.  With a finite
-    max_correspondence_distance the searches also end at the cube that covers that distance."""
+    """A target of more than 4 M points, queries inside, around and far outside it: a wave does
+    not scan such a cloud point by point, it samples it and searches the ball of the distance the
+    sample gives.  With a finite max_correspondence_distance the searches also end at the cube
+    that covers that distance."""
     tx, ty, tz = gen.uniform_cloud(4_300_000, 21, 0, 100)
     rng = np.random.default_rng(9)
     q = np.concatenate([
@@ -810,6 +811,7 @@ def test_correspondences_bounded_on_a_target_beyond_the_whole_grid_scan(hip, ora
         rt, rd, rn = oracle.find_correspondences(q[:, 0], q[:, 1], q[:, 2], tx, ty, tz, max_d, algo=1)
         assert n == rn and np.array_equal(t, rt)
         assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+        assert ix.last_stats()["brute"] == 0
     ix.close()
 
 
@@ -823,15 +825,16 @@ def test_knn_strays_around_a_large_cloud(hip, oracle):
         rng.uniform(0, 100, size=(500, 3)),       # inside the cloud
         rng.uniform(-3, 103, size=(500, 3)),      # around its faces
         rng.uniform(-400, 500, size=(200, 3)),    # far outside
-        np.array([[50.0, 50.0, 5000.0], [-1e4, -1e4, -1e4], [3e9, 0.0, -2e12]]),
+        np.array([[50.0, 50.0, 5000.0], [-1e4, -1e4, -1e4], [3e9, 0.0, -2e12], [1e30, 1e30, -1e30]]),
     ]).astype(F)
     ix = hip.Index(tx, ty, tz, k_hint=16, algo=2)
     for k in (16, 5):
         idx, dist, cnt = ix.knn(q[:, 0], q[:, 1], q[:, 2], k)
         st = ix.last_stats()
-        # (the last query is so far away that every point of the cloud is at the same f32
-        # distance from it: more ties than the retry stage lists, the one brute-force query)
-        assert st["grid_ring"] >= 200 and st["brute"] <= 1
+        # (the last two queries are so far away that every point of the cloud is at the same f32
+        # distance from them, +inf for the last: more ties than the retry stage lists, the two
+        # brute-force queries)
+        assert st["grid_ring"] >= 200 and st["brute"] <= 2
         ridx, rdist, _, rcnt = oracle.knn(tx, ty, tz, q[:, 0], q[:, 1], q[:, 2], k, algo=1)
         assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
         assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))

@@ -18,6 +18,8 @@
 // and finally by the brute-force kernel, so the result is exact for every input.
 #include <cstdlib>
 
+#include <cstring>
+
 #include "knn_common.h"
 
 #pragma clang fp contract(off)
@@ -256,9 +258,10 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_hist_kernel(const float *x,
                                                                  uint32_t *zero_word,
                                                                  uint32_t *zero_block) {
     // the first kernel of a sort clears what the later ones accumulate into: the non-empty-cell
-    // counter (fine_sort_kernel) and, for an index, the 32 stage counters of its searches
+    // counter and the sum of squared cell counts behind it (fine_sort_kernel) and, for an index,
+    // the 32 stage counters of its searches
     if (blockIdx.x == 0) {
-        if (zero_word && threadIdx.x == 0) *zero_word = 0u;
+        if (zero_word && threadIdx.x < 4) zero_word[threadIdx.x] = 0u;  // count + sum of squares
         if (zero_block && threadIdx.x < 32) zero_block[threadIdx.x] = 0u;
     }
     extern __shared__ uint32_t hist[];
@@ -366,11 +369,13 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     const uint32_t ipt = (cpb + GB_THREADS - 1) / GB_THREADS;
     const uint32_t f0 = threadIdx.x * ipt;
     uint32_t local = 0, opened = 0;
+    unsigned long long squares = 0;  // sum of squared cell counts = points x occupancy seen by a point
     for (uint32_t j = 0; j < ipt; ++j) {
         const uint32_t f = f0 + j;
         if (f < cpb) {
             local += cnt[f];
             opened += cnt[f] ? 1u : 0u;
+            squares += (unsigned long long)cnt[f] * cnt[f];
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -380,13 +385,24 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
         if (lane >= off) incl += o;
     }
     __shared__ uint32_t wopen[GB_THREADS / 64];
+    __shared__ unsigned long long wsq[GB_THREADS / 64];
     if (lane == 63) wsum[wave] = incl;
-    for (int off = 32; off > 0; off >>= 1) opened += __shfl_down(opened, off, 64);
-    if (lane == 0) wopen[wave] = opened;
+    for (int off = 32; off > 0; off >>= 1) {
+        opened += __shfl_down(opened, off, 64);
+        squares += __shfl_down(squares, off, 64);
+    }
+    if (lane == 0) {
+        wopen[wave] = opened;
+        wsq[wave] = squares;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {  // one atomic per block
+    if (threadIdx.x == 0) {  // one atomic each per block; nonempty + 2 is 8-byte aligned
         const uint32_t o = wopen[0] + wopen[1] + wopen[2] + wopen[3];
-        if (o) atomicAdd(nonempty, o);
+        if (o) {
+            atomicAdd(nonempty, o);
+            atomicAdd(reinterpret_cast<unsigned long long *>(nonempty + 2),
+                      wsq[0] + wsq[1] + wsq[2] + wsq[3]);
+        }
     }
     uint32_t run = begin + incl - local;
     for (int w = 0; w < wave; ++w) run += wsum[w];
@@ -475,8 +491,6 @@ struct CellArgs {
     int n_radii;            // entries of wave_radii in use
     float useful_d2;        // 1-NN only: neighbours beyond this squared distance are of no use
                             // to the caller (+inf = no such bound)
-    uint32_t all_gate;      // the fifth radius (the whole grid) only when at most this many
-                            // queries entered the launch
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
@@ -836,8 +850,8 @@ __device__ __forceinline__ void clipped_row(const GridGeom &g, const BallClip &c
     const float rem = clip.r * clip.r - (gy * gy + gz * gz);
     if (rem >= 0.0f) {
         const float xr = sqrtf(rem);
-        *xa = max(x0, (int)fmaxf(floorf((clip.ux - xr) * g.inv), -1.0f));
-        *xb = min(x1, (int)fminf(floorf((clip.ux + xr) * g.inv), 2048.0f));
+        *xa = max(x0, (int)fmaxf(floorf((clip.ux - xr) * g.inv), -1.0f));  // (int) of a huge float is undefined
+        *xb = min(x1, (int)fminf(floorf((clip.ux + xr) * g.inv), 1e9f));
     } else {
         *xb = x0 - 1;
     }
@@ -973,10 +987,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
     const uint32_t total = *a.qcount;
     const GridGeom &g = a.g;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // One wave scanning every point answers a stray query (an outlier far from the cloud) in
-    // microseconds, where the tiled brute-force kernel would keep a single lane on it for the
-    // whole cloud; with very many such queries that kernel fills the GPU and takes over.
-    const int n_radii = (a.n_radii == 5 && total > a.all_gate) ? 4 : a.n_radii;
+    const int n_radii = a.n_radii;
 
     for (uint32_t pos = blockIdx.x * WAVES + w; pos < total; pos += gridDim.x * WAVES) {
         const uint32_t entry = a.qlist[pos];
@@ -1814,7 +1825,16 @@ double target_occupancy(uint32_t k_hint) {
     return p;
 }
 
-constexpr double kMaxDim = 1024.0;
+// Where the sort's four statistics words live behind cell_start[0 .. ncell]: the number of
+// non-empty cells, a spare word and the 64-bit sum of squared cell counts (8-byte aligned).
+static inline size_t nonempty_slot(uint32_t ncell) { return ((size_t)ncell + 2) & ~(size_t)1; }
+
+// cells per axis at most (experiments may override it: PCRS_GRID_MAXDIM)
+static const double kMaxDim = [] {
+    const char *e = getenv("PCRS_GRID_MAXDIM");
+    const double v = e ? atof(e) : 0.0;
+    return v >= 16.0 && v <= 65536.0 ? v : 1024.0;
+}();
 
 // Geometry for a requested cell edge: dims per axis (capped), cell enlarged until the cell count
 // fits the budget and every capped axis still covers its extent.
@@ -1952,6 +1972,10 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     //    are much fuller than the target (surfaces and clusters leave most of the box empty).
     //    Every attempt takes the full histogram with cell ids, so the accepted one is reused.
     const double P = target_occupancy(k_hint);
+    static const bool weighted_occupancy = [] {  // experiments only: PCRS_GRID_WEIGHTED=0
+        const char *e = getenv("PCRS_GRID_WEIGHTED");
+        return !(e && e[0] == '0');
+    }();
     double eff[3];
     for (int a = 0; a < 3; ++a) eff[a] = ext[a] > 1e-3 * emax ? ext[a] : 1e-3 * emax;
     double cell = cbrt(eff[0] * eff[1] * eff[2] * P / (double)nvalid);
@@ -1979,7 +2003,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         double used = cell;
         make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
         cell = used;
-        uint32_t *d_nonempty = counts.as<uint32_t>() + ncell + 1;
+        uint32_t *d_nonempty = counts.as<uint32_t>() + nonempty_slot(ncell);
         SortPlan sp{};
         const bool two_level = plan_sort(g, ncell, m, &sp);
         if (two_level) {
@@ -2003,7 +2027,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
                                         sorted3.as<float>(), ix->counters.as<uint32_t>()));
         } else {
             if (!cell_id.p) PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
-            PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 2) * sizeof(uint32_t),
+            PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 6) * sizeof(uint32_t),
                                                ctx->stream));
             hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
                                ix->y, ix->z, m, g, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
@@ -2011,10 +2035,21 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         }
         sorted_done = two_level;
         if (attempt == 3 || fixed_cell) break;
-        PCRS_TRY(pcrs_launch_publish(ctx, d_nonempty, h_nonempty, sizeof(uint32_t)));
+        PCRS_TRY(pcrs_launch_publish(ctx, d_nonempty, h_nonempty, 4 * sizeof(uint32_t)));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t nonempty = *h_nonempty;
-        const double occ = (double)nvalid / (double)(nonempty ? nonempty : 1);
+        double occ = (double)nvalid / (double)(nonempty ? nonempty : 1);
+        if (two_level && weighted_occupancy) {
+            // What a search pays for is the occupancy a *point* sees, sum(c^2) / n (uniform
+            // clouds: one more than the mean).  A scan that is dense near the sensor and sparse
+            // far out has a modest mean over its occupied cells and hundreds of points in the
+            // cells where most of its points are; the sparse part then takes the retry stage,
+            // which is the cheaper of the two.
+            unsigned long long squares;
+            memcpy(&squares, h_nonempty + 2, sizeof(squares));
+            const double seen = (double)squares / (double)nvalid - 1.0;
+            if (seen > occ) occ = seen;
+        }
         if (occ <= 1.6 * P) break;
         // occupied volume ~ nonempty * cell^3: re-aim at P points per occupied cell.  A surface
         // responds with cell^2 rather than cell^3, hence the repeated attempts.
@@ -2385,7 +2420,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
             PCRS_HIP_CHECK(ctx, q_tmp.alloc(ctx, (size_t)nq * sizeof(float4)));
             PCRS_HIP_CHECK(ctx, q_sorted.alloc(ctx, (size_t)nq * sizeof(float4)));
             PCRS_HIP_CHECK(ctx, q_cells.alloc(ctx, ((size_t)ix->ncell + 8) * sizeof(uint32_t)));
-            uint32_t *q_nonempty = q_cells.as<uint32_t>() + ix->ncell + 1;
+            uint32_t *q_nonempty = q_cells.as<uint32_t>() + nonempty_slot(ix->ncell);
             PCRS_TRY(run_two_level_sort(ctx, q.qx, q.qy, q.qz, nq, sp, q_table.as<uint32_t>(),
                                         q_sums.as<uint32_t>(), q_tmp.as<float4>(),
                                         q_sorted.as<float4>(), q_cells.as<uint32_t>(), q_nonempty));
@@ -2419,13 +2454,12 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     // The list ends with the whole grid as the last "cube": for the queries that are left (points
     // far from the cloud) a wave costs far less than the tiled brute-force kernel, where a single
     // lane would work through the whole cloud.  The retries sample large regions and then search
-    // a ball, so the size of the cloud does not matter to them.  1-NN searches need no
-    // brute-force launch at all; longer lists keep it for tie overflows and for floods of stray
-    // queries (all_gate).
+    // a ball, so neither the size of the cloud nor the number of such queries matters to them.
+    // 1-NN searches need no brute-force launch at all; longer lists keep it for more ties at the
+    // K-th distance than a wave lists.
     const bool wave_does_all = nn_only;  // one neighbour: no list can overflow
     a.wave_radii[4] = 1 << 20;
     a.n_radii = 5;
-    a.all_gate = nn_only ? 0xFFFFFFFFu : 65536u;
     if (nn_only) {
         // the 1-NN kernel retries in place (a wave per failed query, right behind the wave's own
         // first stage): what it still cannot certify goes straight to the brute-force list

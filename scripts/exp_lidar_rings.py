@@ -10,7 +10,7 @@ import numpy as np
 from pointclouds_rs import hip
 
 rng = np.random.default_rng(11)
-for sweeps in (1, 8):
+for sweeps in ([int(a) for a in sys.argv[1:]] or [1, 8]):
     beams, az = 64, 2048
     elev = np.deg2rad(np.linspace(-24.8, -1.0, beams))      # below the horizon: ground hits
     r = 1.73 / np.tan(-elev)                                # 3.7 m ... 99 m

@@ -5,9 +5,9 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/prof_script
 rm -rf "$out"; mkdir -p "$out"
-script=$R/$1
+script=$R/$1; shift
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace -d "$out/trace" -o kt -- python3 "$script" > "$out/trace.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace -d "$out/trace" -o kt -- python3 "$script" "$@" > "$out/trace.log" 2>&1 || exit 1
 python3 - "$out" <<'PY'
 import sqlite3, sys, glob, collections
 db = sqlite3.connect(glob.glob(sys.argv[1] + "/trace/**/*_results.db", recursive=True)[0])

@@ -15,5 +15,6 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -- python3 $a
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -- python3 $args > "$out/pmc_write.log" 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d "$out/pmc_sq1" -- python3 $args > "$out/pmc_sq1.log" 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d "$out/pmc_sq2" -- python3 $args > "$out/pmc_sq2.log" 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE -d "$out/pmc_ta" -- python3 $args > "$out/pmc_ta.log" 2>&1 || exit 1
 grep "^{" "$out/trace.log" | cut -c1-300
 echo profiled

@@ -824,325 +824,6 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
     }
 }
 
-// ----------------------------------------------------------------- query kernel, by counting
-//
-// The same lane-per-query search with the selection done by counting instead of by insertion.
-// knn_cell_kernel pushes every candidate of the cube through a K-deep v_med3 chain (17 of its 23.5
-// vector instructions per candidate at K = 17) although nine candidates in ten are farther than the
-// K-th neighbour.  Here the first walk only counts: each squared distance goes into a per-lane
-// histogram in LDS (quarter-octave bins taken from the exponent and two mantissa bits of the f32:
-// shift, subtract, clamp, address, one ds_add).  The bin in which the running count reaches K gives
-// an upper edge; the second walk appends the candidates below that edge -- K plus the few that share
-// the last bin -- to a list in LDS, and only those go through the insertion chain.
-//
-// LDS: the histogram (HIST_BINS words per lane) and the lists share one pool per wave.  The exact
-// list lengths are known from the counts before the second walk starts, so the lists are laid out
-// back to back (a prefix sum over the wave) and the pool need only hold the wave's average.
-//
-// Identities: the chain orders keys made of the distance's upper 27 bits and the candidate's
-// position in the list (low 5 bits), so the sorted registers say at once which list entry holds
-// the r-th neighbour.  Two neighbours whose distances agree in those 27 bits are a pair the
-// truncated key may have put in the wrong order: an isolated pair is put right by comparing the
-// full (distance, index) keys, anything longer -- and a pair that straddles the K-th place -- goes
-// to the retry list, as does a lane whose list does not fit.
-constexpr int HIST_BINS = 26;
-constexpr uint32_t HIST_LIST_MAX = 32;   // list positions must fit the 5 low key bits
-constexpr uint32_t HIST_EMPTY = 0xFFFFFFFFu;
-
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// This lane's neighbours: lst[] (LDS) holds the sorted slots of its candidates in walk order,
-// the low 5 bits of D[r] the list position of the r-th neighbour.
-template <int KC>
-struct PoolNbrs {
-    const uint32_t (&D)[KC];
-    const uint32_t *lst;
-    const float4 *spts;
-    float qx, qy, qz;
-    __device__ __forceinline__ PoolNbrs(const uint32_t (&d)[KC], const uint32_t *l, const float4 *s,
-                                        float x, float y, float z)
-        : D(d), lst(l), spts(s), qx(x), qy(y), qz(z) {}
-    __device__ __forceinline__ uint64_t key_of(const float4 &p) const {
-        return make_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
-    }
-    template <class F>
-    __device__ __forceinline__ void for_each(uint32_t c, F f) const {
-        if (c == 0u) return;
-#pragma unroll
-        for (int r = 0; r + 1 < KC; r += 4) {
-            uint32_t s[4];
-            float4 p[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)  // ranks past the end repeat the first (a valid entry)
-                if (r + i + 1 < KC) s[i] = lst[((uint32_t)(r + i) < c ? D[r + i] : D[0]) & 31u];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (r + i + 1 < KC) p[i] = spts[s[i]];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (r + i + 1 < KC)
-                    if ((uint32_t)(r + i) < c) f((uint32_t)(r + i), key_of(p[i]), s[i]);
-        }
-    }
-    __device__ __forceinline__ void fetch(uint64_t, uint32_t slot, float &x, float &y,
-                                          float &z) const {
-        const float4 p = spts[slot];
-        x = p.x;
-        y = p.y;
-        z = p.z;
-    }
-};
-
-template <int K, bool COLLECT>
-__global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(6)))
-void knn_hist_kernel(CellArgs a, KnnOut out) {
-    constexpr int NB = HIST_BINS;
-    constexpr int KC = K + 1;  // one more than asked for: the neighbour behind the last place
-    constexpr uint32_t POOL = (uint32_t)NB * 64u;
-    __shared__ uint32_t pool[GB_THREADS / 64][NB * 64];
-
-    if (a.zero_me && blockIdx.x == 0 && threadIdx.x < 16) a.zero_me[threadIdx.x] = 0u;
-    if (a.skip && *a.skip) return;
-    uint32_t total = a.nq;
-    if (a.qmode >= 2) total = *a.qcount;
-    const GridGeom &g = a.g;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t *const hw = pool[threadIdx.x >> 6];
-    uint32_t *const hl = hw + lane;  // this lane's column of the histogram
-    // Bin NB-1 starts at (2 cells)^2 -- no certified K-th distance of a 27-cell cube is that large
-    // -- and bins NB-2 ... 1 are the quarter octaves below it; bin 0 takes everything smaller.
-    const int t0 = (int)(__float_as_uint(4.0f * g.cell * g.cell) >> 21) - (NB - 1);
-    const uint32_t keff = a.kcert;
-
-    const uint32_t stride = gridDim.x * GB_THREADS;
-    for (uint32_t base = xcd_contiguous_block(blockIdx.x, gridDim.x) * GB_THREADS; base < total;
-         base += stride) {  // the whole wave stays in the loop: it allocates its lists together
-        const uint32_t pos = base + threadIdx.x;
-        bool live = pos < total;
-        uint32_t qi = 0;
-        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-        if (live) {
-            if (a.qmode == 0 || a.qmode == 3) {
-                const float4 p = a.spts[a.qmode == 3 ? a.qlist[pos] : pos];
-                const uint32_t orig = __float_as_uint(p.w);
-                live = orig - a.q_begin < a.q_len;  // else not a query of this call
-                qi = orig - a.q_begin;
-                qx = p.x;
-                qy = p.y;
-                qz = p.z;
-            } else if (a.qmode == 4) {
-                const float4 p = a.qpts[pos];
-                qi = __float_as_uint(p.w);
-                qx = p.x;
-                qy = p.y;
-                qz = p.z;
-            } else {
-                qi = (a.qmode == 2) ? a.qlist[pos] : pos;
-                qx = a.qx[qi];
-                qy = a.qy[qi];
-                qz = a.qz[qi];
-            }
-        }
-        if (live && !finite3(qx, qy, qz)) {  // no neighbours: the consumers write their defaults
-            uint64_t none[1] = {PCRS_EMPTY_KEY};
-            consume<true>(RegNbrs<1>(none, a.rx, a.ry, a.rz), 0u, false, (size_t)qi, qx, qy, qz,
-                          out);
-            live = false;
-        }
-        auto fail = [&]() {
-            if (a.fail_list) {
-                const uint32_t f = atomicAdd(a.fail_count, 1u);
-                a.fail_list[f] = qi;
-            }
-            live = false;
-        };
-        const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
-        const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
-        const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
-        const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
-        const pcrs_f2 qxy = {qx, qy};
-        const pcrs_q3 q3 = make_q3(qx, qy, qz);
-
-        // ---- walk 1: count the candidates by distance
-#pragma unroll
-        for (int i = 0; i < NB; ++i) hl[i * 64] = 0u;
-        if (live) {
-            auto count = [&](float d2) {
-                int b = (int)(__float_as_uint(d2) >> 21) - t0;
-                b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
-                __hip_atomic_fetch_add(hl + b * 64, 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
-            };
-            walk_cube3(
-                a, cx, cy, cz, q3,
-                [&](const float(&d2)[4], uint32_t) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) count(d2[j]);
-                },
-                [&](const pcrs_p3 &p, uint32_t, bool lv) {
-                    const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
-                    if (lv) count(d2);
-                });
-        }
-        // the bin in which the count reaches keff, and how many candidates lie up to its edge
-        uint32_t cnt = 0, edge = 0x7F800000u;  // every finite distance is below +inf's pattern
-        {
-            uint32_t acc = 0;
-            bool found = false;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                acc += hl[i * 64];
-                if (!found && acc >= keff) {
-                    found = true;
-                    cnt = acc;
-                    if (i < NB - 1) edge = (uint32_t)(i + t0 + 1) << 21;
-                }
-            }
-            if (!found) cnt = acc;  // fewer than keff points in the cube: all of them
-        }
-        if (!live) cnt = 0;
-        if (cnt > HIST_LIST_MAX) {
-            fail();
-            cnt = 0;
-        }
-        // lists back to back in the wave's pool (which was the histogram until here)
-        uint32_t off = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(off, d, 64);
-            if (lane >= (uint32_t)d) off += v;
-        }
-        off -= cnt;
-        if (live && off + cnt > POOL) {
-            fail();
-            cnt = 0;
-        }
-        if (!live) continue;  // nothing below needs the other lanes
-        uint32_t *const my = hw + off;
-
-        // ---- walk 2: list what lies below the edge (slots, or the distances themselves)
-        uint32_t h = 0;
-        auto take = [&](float d2, uint32_t slot) {
-            const uint32_t bits = __float_as_uint(d2);
-            if (bits < edge && h < cnt) {
-                my[h] = COLLECT ? slot : bits;
-                ++h;
-            }
-        };
-        walk_cube3(
-            a, cx, cy, cz, q3,
-            [&](const float(&d2)[4], uint32_t slot) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) take(d2[j], slot + j);
-            },
-            [&](const pcrs_p3 &p, uint32_t slot, bool lv) {
-                const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
-                if (lv) take(d2, slot);
-            });
-
-        // ---- the insertion chain over the listed candidates only
-        uint32_t D[KC];
-#pragma unroll
-        for (int i = 0; i < KC; ++i) D[i] = HIST_EMPTY;
-        auto insert = [&](uint32_t key) {
-#pragma unroll
-            for (int s = KC - 1; s > 0; --s) D[s] = umed3(key, D[s - 1], D[s]);
-            D[0] = D[0] < key ? D[0] : key;
-        };
-        if constexpr (COLLECT) {
-            const pcrs_p3 *p3 = reinterpret_cast<const pcrs_p3 *>(a.spts3);
-            for (uint32_t j = 0; j < h; j += 4) {
-                pcrs_p3 c[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c[i] = p3[my[j + i < h ? j + i : j]];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t bits = __float_as_uint(sqdist(qx, qy, qz, c[i].x, c[i].y, c[i].z));
-                    insert(j + i < h ? ((bits & ~31u) | (j + i)) : HIST_EMPTY);
-                }
-            }
-        } else {
-            for (uint32_t j = 0; j < h; j += 4) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) insert(j + i < h ? my[j + i] : HIST_EMPTY);
-            }
-        }
-        uint32_t nv = 0;  // neighbours found, at most K
-#pragma unroll
-        for (int i = 0; i < K; ++i) nv += D[i] != HIST_EMPTY ? 1u : 0u;
-
-        if constexpr (COLLECT) {
-            // pairs whose truncated keys may be in the wrong order
-            bool unsure = false;
-#pragma unroll
-            for (int i = 0; i < K; ++i)
-                if ((uint32_t)i < keff && D[i + 1] != HIST_EMPTY) unsure |= (D[i] ^ D[i + 1]) < 32u;
-            if (unsure) {
-                fail();
-                continue;
-            }
-        }
-
-        // ---- certification: every point outside the cube is farther than `margin`
-        const int R = a.R;
-        const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
-                           (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
-        bool certified = whole;
-        if (!whole) {
-            // the keff-th distance (rounded up to the key's resolution); NaN when there is none
-            uint32_t tb = HIST_EMPTY;
-#pragma unroll
-            for (int i = 0; i < K; ++i)
-                if ((uint32_t)i == keff - 1) tb = D[i];
-            const float tau_cert = __uint_as_float(COLLECT ? (tb | 31u) : tb);
-            float margin = __builtin_inff();
-            const float u[3] = {ux, uy, uz};
-            const int c[3] = {cx, cy, cz};
-            const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                if (c[ax] + R < n[ax] - 1)
-                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-            }
-            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
-            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
-            certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
-        }
-        if (!certified) {
-            fail();
-            continue;
-        }
-
-        if constexpr (COLLECT) {
-            const uint32_t have = nv < keff ? nv : keff;
-            consume<true>(PoolNbrs<KC>(D, my, a.spts, qx, qy, qz), have, true, (size_t)qi, qx, qy,
-                          qz, out);
-        } else {
-            // SOR mean straight from the sorted distances (statistical_outlier.rs:28-37)
-            if (out.mean) {
-                const uint32_t kk = out.k_sor + 1u;
-                const uint32_t c = nv < kk ? nv : kk;
-                const uint32_t first = c > 1u ? 1u : 0u;
-                float mean = __builtin_inff();
-                if (c - first > 0u) {
-                    float sum = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < K; ++i)
-                        if ((uint32_t)i >= first && (uint32_t)i < c) sum += sqrtf(__uint_as_float(D[i]));
-                    mean = sum / (float)(c - first);
-                }
-                KnnOut o2 = out;
-                store_mean(o2, qi, mean);
-            }
-        }
-    }
-}
-
 // Wave-cooperative walk over the rows of a box of cells: f(p, valid, slot) is called by the whole
 // wave for every 64-point piece of the box.  The lanes fetch the row ranges in parallel (one
 // memory latency for up to 64 rows) and a scan of the row lengths turns the rows into one list;
@@ -2689,31 +2370,6 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
             hipLaunchKernelGGL((knn_cell_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
                                ctx->stream, a, out);                                            \
     } while (0)
-        // 12 to 17 neighbours: selection by counting (knn_hist_kernel); shorter lists are cheap
-        // to insert into, longer ones do not fit its 32-entry candidate lists
-        static const bool use_hist = [] {
-            const char *e = getenv("PCRS_HIST");
-            return !(e && e[0] == '0');
-        }();
-        if (use_hist && (kb == 12 || kb == 16 || kb == 17)) {
-#define PCRS_HIST_CALL(KK)                                                                      \
-    do {                                                                                        \
-        if (collect)                                                                            \
-            hipLaunchKernelGGL((knn_hist_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0,  \
-                               ctx->stream, a, out);                                            \
-        else                                                                                    \
-            hipLaunchKernelGGL((knn_hist_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
-                               ctx->stream, a, out);                                            \
-    } while (0)
-            if (kb == 12)
-                PCRS_HIST_CALL(12);
-            else if (kb == 16)
-                PCRS_HIST_CALL(16);
-            else
-                PCRS_HIST_CALL(17);
-#undef PCRS_HIST_CALL
-            return;
-        }
         PCRS_DISPATCH_K(kb, PCRS_CELL_CALL)
 #undef PCRS_CELL_CALL
     };

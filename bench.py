@@ -43,7 +43,8 @@ HBM_PEAK_GBPS = 8000.0
 VALU_PEAK_TOPS = 78.6
 N_XCD, N_SIMD = 8, 1024  # MI355X: 8 XCDs, 256 CUs x 4 SIMDs
 METRIC = "Mpoints/sec through SOR k=16 + normals on 1M-pt cloud; ICP iters/sec"
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r02d"
+SEARCH_KERNEL = "knn_tag_kernel<17>"  # the dominant kernel of the default workload
 
 
 # --------------------------------------------------------------------------------- CPU legs
@@ -280,8 +281,9 @@ def run_sor_normals(args):
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None,
-                "kernel": "knn_cell_kernel<17, true>: neighbour search over every query, fused with the SOR "
-                          "mean and the covariance of the PCA normal",
+                "kernel": SEARCH_KERNEL + ": neighbour search over every query (one walk of the 27-cell "
+                          "cube, insertion chain over distance keys tagged with the candidate's ordinal), "
+                          "fused with the SOR mean and the covariance of the PCA normal",
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_launches": launches,
                 "algorithmic_bytes_per_launch": BYTES_PER_POINT * nq,
@@ -313,7 +315,7 @@ def profile_counters(avg_kernel_s):
     are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced
     reads, so the read side is doubled (an upper bound for this kernel's per-lane 16-byte loads)."""
     out = {"traffic": None}
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG,):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json")
         try:
             with open(path) as f:
@@ -322,7 +324,7 @@ def profile_counters(avg_kernel_s):
             continue
         meta = d.get("_meta", {})
         for name, c in d.items():
-            if "knn_cell_kernel<17, true>" not in name:
+            if SEARCH_KERNEL not in name:
                 continue
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 rd = c["FETCH_SIZE"]["mean_per_launch"] * 1024.0
@@ -350,7 +352,7 @@ def profile_counters(avg_kernel_s):
                     # quad-cycles (an unpacked f32 instruction holds its SIMD for one), summed over
                     # the 1024 SIMDs; GRBM_GUI_ACTIVE counts the launch's cycles once per XCD.  `peak`
                     # above is the packed-f32 rate (two lane-ops per lane and quad-cycle): a kernel
-                    # of unpacked instructions, like this one's v_med3_f32 chain, tops out at half.
+                    # of unpacked instructions, like this one's v_med3 chain, tops out at half.
                     quads = c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / N_XCD / 4.0
                     v["issue_busy"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / (N_SIMD * quads)
                     v["peak_unpacked"] = VALU_PEAK_TOPS / 2.0

@@ -494,6 +494,8 @@ struct CellArgs {
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
+    uint32_t *alt_list;     // one-walk kernel: queries it hands to the two-walk kernel (a cube of
+    uint32_t *alt_count;    // too many candidates for its tags, a run of tied distances)
     uint32_t *stage1_fail;  // 1-NN kernel (it retries in place): counts what its first stage left
     uint32_t kcert;         // neighbours that must be certified (<= K)
     uint32_t kcollect;      // neighbours whose identity is needed (pass 2), 0 = none
@@ -559,9 +561,13 @@ __device__ __forceinline__ void walk_cube(const CellArgs &a, int cx, int cy, int
 struct pcrs_p3 {
     float x, y, z;
 };
-template <class F4, class F1>
+struct EveryRow {
+    __device__ __forceinline__ bool operator()(uint32_t) const { return true; }
+};
+// row(points in the row) is asked before each row; false ends the walk there.
+template <class F4, class F1, class FR = EveryRow>
 __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, int cz,
-                                           const pcrs_q3 &q, F4 f4, F1 f1) {
+                                           const pcrs_q3 &q, F4 f4, F1 f1, FR row_ok = FR()) {
     const GridGeom &g = a.g;
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
     const pcrs_p3 *base = reinterpret_cast<const pcrs_p3 *>(a.spts3);
@@ -574,6 +580,7 @@ __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, in
             const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
             const uint32_t s0 = a.cell_start[row + x0];
             const uint32_t s1 = a.cell_start[row + x1 + 1];
+            if (!row_ok(s1 - s0)) return;
             const pcrs_p3 *pp = base + s0;
             const pcrs_p3 *const pe = base + s1;
             uint32_t slot = s0;  // counted beside the pointer: (pp - base) is a division by 12
@@ -821,6 +828,270 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             consume<true>(LdsNbrs<CAP, GB_THREADS>(lst, ord, a.spts, qx, qy, qz), have, true,
                           (size_t)qi, qx, qy, qz, o2);
         }
+    }
+}
+
+// ------------------------------------------------------- query kernel, one walk with tagged keys
+//
+// knn_cell_kernel walks the cube twice when neighbour identities are needed: the insertion chain
+// of the first walk carries distances only, the second walk finds whom they belong to.  Here the
+// chain carries 32-bit keys made of the distance's upper 22 bits and, in the low 10, the
+// candidate's ordinal in the walk, so one walk yields the K nearest and who they are: no second
+// walk (a fifth of the vector instructions and two fifths of the per-lane loads of the two-walk
+// kernel), no lists in LDS.  The ordinals become sorted slots by going over the nine row ranges
+// once more (cell_start only).
+// Truncating the distance can misorder two neighbours whose distances agree in the upper 22 bits
+// (about one pair in 300): such a pair is put right by comparing the full (distance, index) keys
+// of the two; a run of three or more, or a pair across the K-th place -- where a candidate the
+// chain has already dropped could belong to the answer -- sends the query to the retry list, as
+// does a cube of more than 1024 candidates.  The SOR mean and the covariance are formed from
+// the neighbours' own coordinates afterwards, so their values do not depend on the truncation.
+constexpr uint32_t TAG_MASK = 1023u;
+constexpr uint32_t TAG_INF = 0x7F800000u;  // keys at or above +inf's pattern are "no neighbour"
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Neighbours by sorted slot, in registers; keys are recomputed from the point.
+template <int K>
+struct SlotRegNbrs {
+    const uint32_t (&slot)[K];
+    const float4 *spts;
+    float qx, qy, qz;
+    __device__ __forceinline__ SlotRegNbrs(const uint32_t (&s)[K], const float4 *sp, float x,
+                                           float y, float z)
+        : slot(s), spts(sp), qx(x), qy(y), qz(z) {}
+    __device__ __forceinline__ uint64_t key_of(const float4 &p) const {
+        return make_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+    }
+    template <class F>
+    __device__ __forceinline__ void for_each(uint32_t c, F f) const {
+        if (c == 0u) return;
+#pragma unroll
+        for (int r = 0; r < K; r += 4) {
+            uint32_t s[4];
+            float4 p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)  // ranks past the end repeat the first (a valid slot)
+                if (r + i < K) s[i] = (uint32_t)(r + i) < c ? slot[r + i] : slot[0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (r + i < K) p[i] = spts[s[i]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (r + i < K)
+                    if ((uint32_t)(r + i) < c) f((uint32_t)(r + i), key_of(p[i]), s[i]);
+        }
+    }
+    __device__ __forceinline__ void fetch(uint64_t, uint32_t sl, float &x, float &y, float &z) const {
+        const float4 p = spts[sl];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+    }
+};
+
+#ifndef PCRS_TAG_WPE
+#define PCRS_TAG_WPE 5
+#endif
+template <int K>
+__global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(K <= 17 ? PCRS_TAG_WPE : 1)))
+void knn_tag_kernel(CellArgs a, KnnOut out) {
+    constexpr int KC = K + 2;  // two more than asked for: the neighbours behind the last place
+    if (a.zero_me && blockIdx.x == 0 && threadIdx.x < 16) a.zero_me[threadIdx.x] = 0u;
+    if (a.skip && *a.skip) return;
+    uint32_t total = a.nq;
+    if (a.qmode >= 2) total = *a.qcount;
+    const GridGeom &g = a.g;
+    const uint32_t keff = a.kcert;
+
+    for (uint32_t pos = xcd_contiguous_block(blockIdx.x, gridDim.x) * GB_THREADS + threadIdx.x;
+         pos < total; pos += gridDim.x * GB_THREADS) {
+        uint32_t qi;
+        float qx, qy, qz;
+        if (a.qmode == 0 || a.qmode == 3) {
+            const float4 p = a.spts[a.qmode == 3 ? a.qlist[pos] : pos];
+            const uint32_t orig = __float_as_uint(p.w);
+            if (orig - a.q_begin >= a.q_len) continue;  // not a query of this call
+            qi = orig - a.q_begin;
+            qx = p.x;
+            qy = p.y;
+            qz = p.z;
+        } else if (a.qmode == 4) {
+            const float4 p = a.qpts[pos];
+            qi = __float_as_uint(p.w);
+            qx = p.x;
+            qy = p.y;
+            qz = p.z;
+        } else {
+            qi = (a.qmode == 2) ? a.qlist[pos] : pos;
+            qx = a.qx[qi];
+            qy = a.qy[qi];
+            qz = a.qz[qi];
+        }
+        if (!finite3(qx, qy, qz)) {  // no neighbours: the consumers write their defaults
+            uint64_t none[1] = {PCRS_EMPTY_KEY};
+            consume<true>(RegNbrs<1>(none, a.rx, a.ry, a.rz), 0u, false, (size_t)qi, qx, qy, qz,
+                          out);
+            continue;
+        }
+        auto fail = [&]() {
+            if (a.fail_list) {
+                const uint32_t f = atomicAdd(a.fail_count, 1u);
+                a.fail_list[f] = qi;
+            }
+        };
+        const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+        const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
+        const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
+        const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
+
+        // ---- the walk: K + 1 smallest tagged keys, ascending, branch-free
+        uint32_t D[KC];
+#pragma unroll
+        for (int i = 0; i < KC; ++i) D[i] = 0xFFFFFFFFu;
+        const pcrs_f2 qxy = {qx, qy};
+        const pcrs_q3 q3 = make_q3(qx, qy, qz);
+        auto insert = [&](uint32_t key) {
+#pragma unroll
+            for (int s = KC - 1; s > 0; --s) D[s] = umed3(key, D[s - 1], D[s]);
+            D[0] = D[0] < key ? D[0] : key;
+        };
+        uint32_t ord = 0;  // candidates met so far
+        bool crowded = false;  // more candidates than the tags can name
+        walk_cube3(
+            a, cx, cy, cz, q3,
+            [&](const float(&d2)[4], uint32_t) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    insert((__float_as_uint(d2[j]) & ~TAG_MASK) | ((ord + (uint32_t)j) & TAG_MASK));
+                ord += 4u;
+            },
+            [&](const pcrs_p3 &p, uint32_t, bool live) {
+                const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
+                insert(live ? ((__float_as_uint(d2) & ~TAG_MASK) | (ord & TAG_MASK)) : 0xFFFFFFFFu);
+                ord += live ? 1u : 0u;
+            },
+            [&](uint32_t len) {  // known before the row is walked: a crowded cube is left at once
+                crowded = ord + len > TAG_MASK + 1u;
+                return !crowded;
+            });
+        uint32_t nv = 0;  // neighbours found, at most K
+#pragma unroll
+        for (int i = 0; i < K; ++i) nv += D[i] < TAG_INF ? 1u : 0u;
+
+        // ---- pairs the truncation may have put in the wrong order (bit i: ranks i and i + 1),
+        // up to the pair behind the last place
+        uint32_t near = 0;
+#pragma unroll
+        for (int i = 0; i <= K; ++i)
+            if ((uint32_t)i <= keff && D[i + 1] < TAG_INF && (D[i] ^ D[i + 1]) <= TAG_MASK)
+                near |= 1u << i;
+        // A crowded cube, or three or more neighbours in a row that the truncation cannot tell
+        // apart, is not for this kernel.  The lanes of a wave that say so append together: where
+        // many do (a crowded region, a lattice), they go as a run of neighbouring queries to the
+        // list of the two-walk kernel, which takes such cubes and ties in its stride; a stray few
+        // join the retry list (any launch that finds work costs a wave's lifetime, and the retry
+        // kernel is launched anyway).
+        if (crowded || (near & (near >> 1))) {
+            const unsigned long long m = __ballot(1);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            const bool alt = a.alt_list && cnt >= 8u;
+            uint32_t *const list = alt ? a.alt_list : a.fail_list;
+            uint32_t *const count = alt ? a.alt_count : a.fail_count;
+            if (list) {
+                const int leader = __builtin_ctzll(m);
+                const uint32_t lane = threadIdx.x & 63u;
+                uint32_t first = 0;
+                if ((int)lane == leader) first = atomicAdd(count, cnt);
+                first = __shfl(first, leader, 64);
+                list[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = qi;
+            }
+            continue;
+        }
+        near &= (1u << keff) - 1u;  // the pairs that matter: up to (last place, the one behind it)
+
+        // ---- certification: every point outside the cube is farther than `margin`
+        const int R = a.R;
+        const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
+                           (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
+        bool certified = whole;
+        if (!whole) {
+            // the keff-th distance, rounded up to the key's resolution (+inf when there is none)
+            uint32_t tb = TAG_INF;
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                if ((uint32_t)i == keff - 1 && D[i] < TAG_INF) tb = D[i] | TAG_MASK;
+            const float tau_cert = __uint_as_float(tb);
+            float margin = __builtin_inff();
+            const float u[3] = {ux, uy, uz};
+            const int c[3] = {cx, cy, cz};
+            const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
+                if (c[ax] + R < n[ax] - 1)
+                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
+            }
+            const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
+            const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
+            certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
+        }
+        if (!certified) {
+            fail();
+            continue;
+        }
+
+        // ---- ordinals to sorted slots: the rows again, in the order of the walk
+        uint32_t slot[K + 1];
+#pragma unroll
+        for (int i = 0; i <= K; ++i) slot[i] = 0u;
+        {
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            uint32_t base = 0;
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int zz = cz + dz;
+                if (zz < 0 || zz >= g.nz) continue;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int yy = cy + dy;
+                    if (yy < 0 || yy >= g.ny) continue;
+                    const uint32_t row =
+                        ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                    const uint32_t s0 = a.cell_start[row + x0];
+                    const uint32_t len = a.cell_start[row + x1 + 1] - s0;
+                    const uint32_t delta = s0 - base;
+#pragma unroll
+                    for (int i = 0; i <= K; ++i) {
+                        const uint32_t o = D[i] & TAG_MASK;
+                        if (o - base < len) slot[i] = o + delta;
+                    }
+                    base += len;
+                }
+            }
+        }
+        // an isolated pair: compare the full keys of the two
+        if (near) {
+            auto key_at = [&](uint32_t sl) {
+                const float4 p = a.spts[sl];
+                return make_key(sqdist(qx, qy, qz, p.x, p.y, p.z), __float_as_uint(p.w));
+            };
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if ((near >> i) & 1u) {
+                    if (key_at(slot[i + 1]) < key_at(slot[i])) {
+                        const uint32_t t = slot[i];
+                        slot[i] = slot[i + 1];
+                        slot[i + 1] = t;
+                    }
+                }
+            }
+        }
+        const uint32_t have = nv < keff ? nv : keff;
+        consume<true>(SlotRegNbrs<K + 1>(slot, a.spts, qx, qy, qz), have, true, (size_t)qi, qx, qy,
+                      qz, out);
     }
 }
 
@@ -2301,18 +2572,19 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
 
     // two retry lists (ping-pong) + stage counters
     const size_t list_elems = (size_t)nq + 64;
-    const size_t need = (2 * list_elems + 64) * sizeof(uint32_t);
+    const size_t need = (3 * list_elems + 64) * sizeof(uint32_t);
     if (ix->fail_lists.bytes < need) {
         PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
     }
     uint32_t *listA = ix->fail_lists.as<uint32_t>();
     uint32_t *listB = listA + list_elems;
+    uint32_t *listC = listB + list_elems;  // handed from the one-walk to the two-walk kernel
     if (!ix->counters.p) {
         PCRS_HIP_CHECK(ctx, ix->counters.alloc(ctx, 32 * sizeof(uint32_t)));
         PCRS_HIP_CHECK(ctx, hipMemsetAsync(ix->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
         ix->counter_phase = 0;
     }
-    // [0..3] failures after each cube stage, [4] owned; this search's set is zero (cleared by the
+    // [0..3] failures after each cube stage, [4] owned, [5] handed over; this search's set is zero (cleared by the
     // search before it, or just now), and its first kernel clears the other set
     uint32_t *counters = ix->counters.as<uint32_t>() + 16 * ix->counter_phase;
     uint32_t *counters_next = ix->counters.as<uint32_t>() + 16 * (ix->counter_phase ^ 1);
@@ -2355,6 +2627,13 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.kcollect = (collect || nn_only) ? (kc ? kc : 1) : 0;
     const int kb = k_bucket(keff);
 
+    bool one_walk = false;
+    auto launch_two_walk = [&](unsigned blocks) {
+#define PCRS_CELL2_CALL(KK)                                                                    \
+    hipLaunchKernelGGL((knn_cell_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a, out)
+        PCRS_DISPATCH_K(kb, PCRS_CELL2_CALL)
+#undef PCRS_CELL2_CALL
+    };
     auto launch = [&](unsigned blocks) {
         if (nn_only) {  // eight lanes per query
             hipLaunchKernelGGL(nn_cell_kernel, dim3(blocks * NN_SUB), dim3(GB_THREADS), 0,
@@ -2370,6 +2649,26 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
             hipLaunchKernelGGL((knn_cell_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
                                ctx->stream, a, out);                                            \
     } while (0)
+        // identities of up to 24 neighbours: one walk with tagged keys (knn_tag_kernel)
+        static const bool use_tag = [] {
+            const char *e = getenv("PCRS_ONE_WALK");
+            return !(e && e[0] == '0');
+        }();
+        one_walk = use_tag && collect && kb >= 8 && kb <= 24;
+        if (one_walk) {
+#define PCRS_TAG_CALL(KK)                                                                      \
+    hipLaunchKernelGGL((knn_tag_kernel<KK>), dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a, out)
+            switch (kb) {
+                case 8: PCRS_TAG_CALL(8); break;
+                case 12: PCRS_TAG_CALL(12); break;
+                case 16: PCRS_TAG_CALL(16); break;
+                case 17: PCRS_TAG_CALL(17); break;
+                case 21: PCRS_TAG_CALL(21); break;
+                default: PCRS_TAG_CALL(24); break;
+            }
+#undef PCRS_TAG_CALL
+            return;
+        }
         PCRS_DISPATCH_K(kb, PCRS_CELL_CALL)
 #undef PCRS_CELL_CALL
     };
@@ -2467,11 +2766,23 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         a.fail_count = &counters[3];
         a.stage1_fail = &counters[0];
     }
+    a.alt_list = listC;
+    a.alt_count = &counters[5];
     pcrs_timing_begin(ctx);
     launch(blocks1);
     pcrs_timing_end(ctx);
     a.xform = nullptr;
     a.zero_me = nullptr;
+    a.alt_list = nullptr;
+    a.alt_count = nullptr;
+    if (one_walk) {
+        // what the one-walk kernel handed over (nothing, on most clouds: the launch then ends at
+        // once) is answered by the two-walk kernel; its failures join the same retry list
+        a.qmode = 2;
+        a.qlist = listC;
+        a.qcount = &counters[5];
+        launch_two_walk(std::min(blocks1, (unsigned)ctx->num_cus * 8u));
+    }
     const bool timing_was = ctx->timing;
     ctx->timing = false;  // the retry stages below are not separate measurements
 

@@ -187,7 +187,7 @@ class Context:
 
     def __del__(self):
         # at interpreter shutdown the HIP runtime may already be gone: the process frees it all
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():  # module globals are cleared late in shutdown
             return
         try:
             self.close()

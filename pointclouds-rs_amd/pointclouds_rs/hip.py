@@ -63,7 +63,7 @@ class Index:
 
     def __del__(self):
         # at interpreter shutdown the HIP runtime may already be gone: the process frees it all
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():
             return
         try:
             self.close()
@@ -294,7 +294,7 @@ class Icp:
 
     def __del__(self):
         # at interpreter shutdown the HIP runtime may already be gone: the process frees it all
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():
             return
         try:
             self.close()

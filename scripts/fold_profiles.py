@@ -27,7 +27,7 @@ dirty = subprocess.call(["git", "-C", ROOT, "diff", "--quiet", "--", "pointcloud
 kernel_ms = None
 for name, calls, total_us, avg_us, pct in con.execute(
         "select name,total_calls,total_duration,average,percentage from top_kernels"):
-    if "knn_cell_kernel<17, true>" in name:
+    if "knn_tag_kernel<17>" in name:
         kernel_ms = avg_us / 1000.0
 out["_meta"] = {"commit": commit + ("+uncommitted kernel changes" if dirty else ""), "kernel_ms": kernel_ms,
                 "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stages --icp-iters 0"}

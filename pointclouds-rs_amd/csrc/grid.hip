@@ -966,13 +966,13 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
             a, cx, cy, cz, q3,
             [&](const float(&d2)[4], uint32_t) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    insert((__float_as_uint(d2[j]) & ~TAG_MASK) | ((ord + (uint32_t)j) & TAG_MASK));
+                for (int j = 0; j < 4; ++j)  // ordinals stay below 1024: the row gate sees to it
+                    insert((__float_as_uint(d2[j]) & ~TAG_MASK) | (ord + (uint32_t)j));
                 ord += 4u;
             },
             [&](const pcrs_p3 &p, uint32_t, bool live) {
                 const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
-                insert(live ? ((__float_as_uint(d2) & ~TAG_MASK) | (ord & TAG_MASK)) : 0xFFFFFFFFu);
+                insert(live ? ((__float_as_uint(d2) & ~TAG_MASK) | ord) : 0xFFFFFFFFu);
                 ord += live ? 1u : 0u;
             },
             [&](uint32_t len) {  // known before the row is walked: a crowded cube is left at once
@@ -1046,12 +1046,15 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
         }
 
         // ---- ordinals to sorted slots: the rows again, in the order of the walk
+        // (a candidate of row t has ordinal base_t + its offset in the row: its slot is the
+        // ordinal plus the sum of the steps (s0_t - base_t) - (s0_(t-1) - base_(t-1)) over the
+        // rows that start at or below it)
         uint32_t slot[K + 1];
 #pragma unroll
-        for (int i = 0; i <= K; ++i) slot[i] = 0u;
+        for (int i = 0; i <= K; ++i) slot[i] = D[i] & TAG_MASK;
         {
             const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-            uint32_t base = 0;
+            uint32_t base = 0, shift = 0;
             for (int dz = -1; dz <= 1; ++dz) {
                 const int zz = cz + dz;
                 if (zz < 0 || zz >= g.nz) continue;
@@ -1062,12 +1065,11 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
                         ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
                     const uint32_t s0 = a.cell_start[row + x0];
                     const uint32_t len = a.cell_start[row + x1 + 1] - s0;
-                    const uint32_t delta = s0 - base;
+                    const uint32_t step = (s0 - base) - shift;
 #pragma unroll
-                    for (int i = 0; i <= K; ++i) {
-                        const uint32_t o = D[i] & TAG_MASK;
-                        if (o - base < len) slot[i] = o + delta;
-                    }
+                    for (int i = 0; i <= K; ++i)
+                        slot[i] += (D[i] & TAG_MASK) >= base ? step : 0u;
+                    shift += step;
                     base += len;
                 }
             }

@@ -16,6 +16,9 @@
 //           the full (d2, index) key in registers and runs the fused consumer.
 // Queries that cannot be certified go to a compact list and are retried with a larger cube,
 // and finally by the brute-force kernel, so the result is exact for every input.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include <cstring>
@@ -2272,6 +2275,15 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     PCRS_HIP_CHECK(ctx, counts.alloc(ctx, ((size_t)max_cells + 8) * sizeof(uint32_t)));
     uint32_t *h_nonempty = reinterpret_cast<uint32_t *>(pin);
     bool sorted_done = false;  // the accepted attempt already left cell_start[] and the points
+    // lists of 8 neighbours and more: the aim follows the dimension of the cloud (below)
+    static const bool dim_switch = [] {  // experiments only: PCRS_GRID_DIM=0
+        const char *e = getenv("PCRS_GRID_DIM");
+        return !(e && e[0] == '0');
+    }();
+    const bool dim_aware = dim_switch && k_hint >= 8 && !getenv("PCRS_GRID_OCC");
+    double P_surface = 0.75 * (double)k_hint;
+    P_surface = P_surface < P ? P : (P_surface > 64.0 ? 64.0 : P_surface);
+    double dim = 3.0, prev_cell = 0.0, prev_occ = 0.0;
     for (int attempt = 0;; ++attempt) {
         double used = cell;
         make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
@@ -2323,18 +2335,51 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             const double seen = (double)squares / (double)nvalid - 1.0;
             if (seen > occ) occ = seen;
         }
-        if (occ <= 1.6 * P) break;
-        // occupied volume ~ nonempty * cell^3: re-aim at P points per occupied cell.  A surface
-        // responds with cell^2 rather than cell^3, hence the repeated attempts.
-        double shrink = cbrt(P / occ);
-        if (shrink < 0.4) shrink = 0.4;
-        double next = cell * shrink;
+        static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
+        if (debug)
+            fprintf(stderr, "pcrs grid attempt %d: cell %.5g, %d x %d x %d cells, %u occupied, "
+                            "mean %.2f points per occupied cell, %.2f seen by a point, aim %.2f (dimension "
+                    "%.2f before this attempt)\n",
+                    attempt, cell, g.nx, g.ny, g.nz, nonempty, (double)nvalid / (nonempty ? nonempty : 1),
+                    occ, P, dim);
+        double next;
+        if (dim_aware) {
+            // How the occupancy answers a change of the cell tells what the cloud is: a volume
+            // goes with cell^3, a surface with cell^2.  On a surface the K-th neighbour is
+            // farther away for the same number of points per cell (K = pi r^2 rho instead of
+            // 4/3 pi r^3 rho), so a grid aimed at the volume figure leaves a surface with cells
+            // its 27-cell cubes cannot certify (a flat slab came out at 3.8 points per cell and
+            // half of its queries in the retry stage), while the cube of a surface holds a third
+            // of the cells: it can afford fuller ones.
+            if (prev_cell > 0.0 && prev_occ > 0.0 && occ > 0.0 &&
+                (prev_cell >= 1.25 * cell || cell >= 1.25 * prev_cell)) {
+                dim = log(prev_occ / occ) / log(prev_cell / cell);
+                dim = dim < 2.0 ? 2.0 : (dim > 3.0 ? 3.0 : dim);
+            } else if (attempt == 0) {
+                dim = std::min(g.nx, std::min(g.ny, g.nz)) <= 2 ? 2.0 : 3.0;
+            }
+            prev_cell = cell;
+            prev_occ = occ;
+            const double aim = P + (3.0 - dim) * (P_surface - P);
+            if (occ >= 0.75 * aim && occ <= 1.6 * aim) break;
+            double f = pow(aim / occ, 1.0 / dim);
+            f = f < 0.4 ? 0.4 : (f > 2.5 ? 2.5 : f);
+            next = cell * f;
+        } else {
+            if (occ <= 1.6 * P) break;
+            // occupied volume ~ nonempty * cell^3: re-aim at P points per occupied cell.  A
+            // surface responds with cell^2 rather than cell^3, hence the repeated attempts.
+            double shrink = cbrt(P / occ);
+            if (shrink < 0.4) shrink = 0.4;
+            next = cell * shrink;
+        }
         if (next < emax / kMaxDim) next = emax / kMaxDim;
         GridGeom g2{};
         uint32_t ncell2 = 0;
         double used2 = next;
         make_geometry(lo, ext, emax, next, max_cells, &g2, &ncell2, &used2);
-        if (used2 > 0.95 * cell) break;  // budget or dimension cap reached: keep this geometry
+        // budget or dimension cap reached: keep this geometry
+        if (next < cell ? used2 > 0.95 * cell : used2 < 1.05 * cell) break;
         cell = next;
     }
 

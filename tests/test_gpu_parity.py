@@ -839,3 +839,53 @@ def test_knn_strays_around_a_large_cloud(hip, oracle):
         assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
         assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
     ix.close()
+
+
+def _tie_and_crowd_cloud():
+    """A cloud that takes every side road of the one-walk search kernel: a uniform background,
+    a blob of 3000 points inside one grid cell (cubes of more candidates than the kernel's
+    10-bit ordinals can name), a patch of an integer lattice (runs of equal distances, also across
+    the K-th place), and mirrored pairs around lattice points (isolated pairs of equal distance)."""
+    rng = np.random.default_rng(2024)
+    bg = rng.uniform(0, 40, size=(30000, 3))
+    blob = 20.0 + rng.uniform(0, 0.05, size=(3000, 3))
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"),
+                 -1).reshape(-1, 3) * 0.5 + 2.0
+    centres = rng.uniform(5, 35, size=(2000, 3)).round(2)
+    off = rng.uniform(0.05, 0.3, size=(2000, 3)).round(3)
+    pairs = np.concatenate([centres, centres + off, centres - off])
+    p = np.concatenate([bg, blob, g, pairs]).astype(F)
+    p = p[rng.permutation(len(p))]
+    return tuple(np.ascontiguousarray(p[:, i]) for i in range(3))
+
+
+@pytest.mark.parametrize("k", [8, 12, 16, 17, 21, 24])
+def test_one_walk_kernel_side_roads(hip, oracle, k):
+    """Lists of 8 to 24 neighbours go through the kernel whose insertion chain carries truncated
+    distance keys: pairs it has to re-order by the full keys, runs and crowded cubes it hands
+    over must all end in the oracle's lists, bit for bit."""
+    x, y, z = _tie_and_crowd_cloud()
+    ix = hip.Index(x, y, z, k_hint=k, algo=2)
+    idx, dist, cnt = ix.knn(x, y, z, k)
+    st = ix.last_stats()
+    ix.close()
+    ridx, rdist, _, rcnt = oracle.knn(x, y, z, x, y, z, k, algo=1)
+    assert np.array_equal(cnt, rcnt)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+    assert st["grid_tile"] + st["grid_ring"] + st["brute"] == len(x)
+
+
+def test_one_walk_kernel_consumers(hip, oracle):
+    """The same cloud through the fused consumers: means, threshold and mask bit-exact, normals
+    to the bar of this file."""
+    x, y, z = _tie_and_crowd_cloud()
+    keep, n_keep, thr, nrm = hip.sor_normals(x, y, z, 16, 1.0, 16)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, 16, 1.0, algo=1)
+    assert np.array_equal(keep, rkeep) and n_keep == rn
+    assert F(thr).view(np.uint32) == F(rthr).view(np.uint32)
+    rnrm = oracle.normals(x, y, z, 16, algo=1)
+    # (equal distances make the 16-neighbour set of a lattice point a matter of index order,
+    # which both sides resolve alike: the covariance sums are then the same numbers)
+    for a, b in zip(nrm, rnrm):
+        assert float(np.abs(a - b).max()) <= 1e-5

@@ -6,14 +6,19 @@
 //
 // Query: one query per lane.  Self queries run in sorted-slot order, so the 64 lanes of a wave
 // sit in the same or adjacent cells and their candidate loads hit the same cache lines.  A lane
-// walks the (2R+1)^3 cube of cells around its own cell:
-//   pass 1  keeps the K smallest squared distances in registers with a branch-free
-//           v_med3_f32 chain (no indices, no divergence); this already yields the SOR mean.
-//   check   the result is exact iff the K-th distance is smaller than the distance from the
-//           query to the nearest face of the cube that is not a grid boundary.
-//   pass 2  (only when neighbour identities are needed) walks the cube again, appends the slots
-//           with d2 <= K-th distance to a per-lane LDS list, then orders those few candidates by
-//           the full (d2, index) key in registers and runs the fused consumer.
+// walks the (2R+1)^3 cube of cells around its own cell and keeps the K smallest squared
+// distances in registers with a branch-free v_med3 chain (no divergence); the result is exact
+// iff the K-th distance is smaller than the distance from the query to the nearest face of the
+// cube that is not a grid boundary.  Two kernels do this:
+//   knn_tag_kernel   (neighbour identities needed, 8 <= K <= 24) one walk: the chain carries
+//           32-bit keys of the distance's upper 22 bits and the candidate's ordinal in the walk,
+//           so the sorted registers name the neighbours; pairs the truncation may have misordered
+//           are put right by their full (d2, index) keys, crowded cubes and tie runs are handed
+//           to the other kernel.
+//   knn_cell_kernel  pass 1 keeps plain distances, which already yields the SOR mean; pass 2
+//           (only when identities are needed) walks the cube again, appends the slots with
+//           d2 <= K-th distance to a per-lane LDS list, then orders those few candidates by the
+//           full (d2, index) key and runs the fused consumer.
 // Queries that cannot be certified go to a compact list and are retried with a larger cube,
 // and finally by the brute-force kernel, so the result is exact for every input.
 #include <algorithm>

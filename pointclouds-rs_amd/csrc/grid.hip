@@ -502,6 +502,10 @@ struct CellArgs {
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
+    float *fail_bound;      // lane-per-query kernels, beside fail_list (nullable): an upper bound of
+                            // the query's kcert-th squared distance (+inf = none) -- the kcert-th
+                            // distance among the points the kernel did see
+    const float *qbound;    // wave-per-query kernel, beside qlist (nullable): those bounds
     uint32_t *alt_list;     // one-walk kernel: queries it hands to the two-walk kernel (a cube of
     uint32_t *alt_count;    // too many candidates for its tags, a run of tied distances)
     uint32_t *stage1_fail;  // 1-NN kernel (it retries in place): counts what its first stage left
@@ -726,6 +730,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             if (a.fail_list) {
                 const uint32_t f = atomicAdd(a.fail_count, 1u);
                 a.fail_list[f] = qi;
+                if (a.fail_bound) a.fail_bound[f] = tau_cert;
             }
             continue;
         }
@@ -778,6 +783,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
                 if (a.fail_list) {
                     const uint32_t f = atomicAdd(a.fail_count, 1u);
                     a.fail_list[f] = qi;
+                    if (a.fail_bound) a.fail_bound[f] = tau_cert;
                 }
                 continue;
             }
@@ -946,18 +952,12 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
                           out);
             continue;
         }
-        auto fail = [&]() {
-            if (a.fail_list) {
-                const uint32_t f = atomicAdd(a.fail_count, 1u);
-                a.fail_list[f] = qi;
-            }
-        };
         const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
         const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
         const int cy = cell_coord(qy, g.oy, g.inv, g.ny);
         const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
 
-        // ---- the walk: K + 1 smallest tagged keys, ascending, branch-free
+        // ---- the walk: K + 2 smallest tagged keys, ascending, branch-free
         uint32_t D[KC];
 #pragma unroll
         for (int i = 0; i < KC; ++i) D[i] = 0xFFFFFFFFu;
@@ -1016,7 +1016,9 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
                 uint32_t first = 0;
                 if ((int)lane == leader) first = atomicAdd(count, cnt);
                 first = __shfl(first, leader, 64);
-                list[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = qi;
+                const uint32_t at = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                list[at] = qi;
+                if (!alt && a.fail_bound) a.fail_bound[at] = __builtin_inff();  // nothing known
             }
             continue;
         }
@@ -1027,13 +1029,13 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
         const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
                            (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
         bool certified = whole;
-        if (!whole) {
-            // the keff-th distance, rounded up to the key's resolution (+inf when there is none)
-            uint32_t tb = TAG_INF;
+        // the keff-th distance, rounded up to the key's resolution (+inf when there is none)
+        uint32_t tb = TAG_INF;
 #pragma unroll
-            for (int i = 0; i < K; ++i)
-                if ((uint32_t)i == keff - 1 && D[i] < TAG_INF) tb = D[i] | TAG_MASK;
-            const float tau_cert = __uint_as_float(tb);
+        for (int i = 0; i < K; ++i)
+            if ((uint32_t)i == keff - 1 && D[i] < TAG_INF) tb = D[i] | TAG_MASK;
+        const float tau_cert = __uint_as_float(tb);
+        if (!whole) {
             float margin = __builtin_inff();
             const float u[3] = {ux, uy, uz};
             const int c[3] = {cx, cy, cz};
@@ -1048,8 +1050,12 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
             const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
             certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
         }
-        if (!certified) {
-            fail();
+        if (!certified) {  // the retry starts from what this walk has seen
+            if (a.fail_list) {
+                const uint32_t f = atomicAdd(a.fail_count, 1u);
+                a.fail_list[f] = qi;
+                if (a.fail_bound) a.fail_bound[f] = tau_cert;
+            }
             continue;
         }
 
@@ -1362,6 +1368,22 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         uint32_t n_region = 0;
         bool counted = false;
         float bound = __builtin_inff();  // smallest upper bound of the kcert-th distance so far
+        // The kernel that handed the query on has seen its 27-cell cube: the kcert-th distance
+        // among those points is a bound already, and the search starts with its ball instead of
+        // counting and searching whole cubes (a query whose cube fell a little short of the
+        // certificate costs a step or two of the walk instead of the 125 cells around it).
+        if (a.qbound && K > 1) {
+            const float hint = a.qbound[pos];
+            if (hint < __builtin_inff()) {
+                const float rb = sqrtf(hint) * (1.0f + 4e-6f) + 2.0f * allow;
+                const float cells = ceilf(rb * g.inv);
+                if (cells <= (float)r_last) {
+                    bound = hint;
+                    R = max((int)cells, 1);
+                    clip.r = rb;
+                }
+            }
+        }
 #pragma unroll 1
         for (;;) {
             x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
@@ -2624,13 +2646,14 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
 
     // two retry lists (ping-pong) + stage counters
     const size_t list_elems = (size_t)nq + 64;
-    const size_t need = (3 * list_elems + 64) * sizeof(uint32_t);
+    const size_t need = (4 * list_elems + 64) * sizeof(uint32_t);
     if (ix->fail_lists.bytes < need) {
         PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
     }
     uint32_t *listA = ix->fail_lists.as<uint32_t>();
     uint32_t *listB = listA + list_elems;
     uint32_t *listC = listB + list_elems;  // handed from the one-walk to the two-walk kernel
+    float *boundA = reinterpret_cast<float *>(listC + list_elems);  // beside listA (fail_bound)
     if (!ix->counters.p) {
         PCRS_HIP_CHECK(ctx, ix->counters.alloc(ctx, 32 * sizeof(uint32_t)));
         PCRS_HIP_CHECK(ctx, hipMemsetAsync(ix->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
@@ -2730,6 +2753,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.heavy = nq < PCRS_HEAVY_FLAG ? 2048u : 0xFFFFFFFFu;  // the flag needs bit 31 of the entry
     a.fail_list = listA;
     a.fail_count = &counters[0];
+    a.fail_bound = nn_only ? nullptr : boundA;
     unsigned blocks1 = (unsigned)((nq + GB_THREADS - 1) / GB_THREADS);
     DevBuf own_counts, own_sums, q_table, q_sums, q_tmp, q_sorted, q_cells;
     bool sorted_queries = false;
@@ -2859,8 +2883,10 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
         a.qmode = 2;
         a.qlist = listA;
         a.qcount = &counters[0];
+        a.qbound = boundA;
         a.fail_list = listB;
         a.fail_count = &counters[3];
+        a.fail_bound = nullptr;
         launch_wave(retry_blocks);
     }
     uint32_t *src = listB;

@@ -10,7 +10,7 @@
 // distances in registers with a branch-free v_med3 chain (no divergence); the result is exact
 // iff the K-th distance is smaller than the distance from the query to the nearest face of the
 // cube that is not a grid boundary.  Two kernels do this:
-//   knn_tag_kernel   (neighbour identities needed, 8 <= K <= 24) one walk: the chain carries
+//   knn_tag_kernel   (neighbour identities needed, 2 <= K <= 24) one walk: the chain carries
 //           32-bit keys of the distance's upper 22 bits and the candidate's ordinal in the walk,
 //           so the sorted registers name the neighbours; pairs the truncation may have misordered
 //           are put right by their full (d2, index) keys, crowded cubes and tie runs are handed
@@ -2724,16 +2724,18 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
             hipLaunchKernelGGL((knn_cell_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
                                ctx->stream, a, out);                                            \
     } while (0)
-        // identities of up to 24 neighbours: one walk with tagged keys (knn_tag_kernel)
+        // identities of 2 to 24 neighbours: one walk with tagged keys (knn_tag_kernel)
         static const bool use_tag = [] {
             const char *e = getenv("PCRS_ONE_WALK");
             return !(e && e[0] == '0');
         }();
-        one_walk = use_tag && collect && kb >= 8 && kb <= 24;
+        one_walk = use_tag && collect && kb >= 2 && kb <= 24;
         if (one_walk) {
 #define PCRS_TAG_CALL(KK)                                                                      \
     hipLaunchKernelGGL((knn_tag_kernel<KK>), dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a, out)
             switch (kb) {
+                case 2: PCRS_TAG_CALL(2); break;
+                case 4: PCRS_TAG_CALL(4); break;
                 case 8: PCRS_TAG_CALL(8); break;
                 case 12: PCRS_TAG_CALL(12); break;
                 case 16: PCRS_TAG_CALL(16); break;

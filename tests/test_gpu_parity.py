@@ -859,9 +859,9 @@ def _tie_and_crowd_cloud():
     return tuple(np.ascontiguousarray(p[:, i]) for i in range(3))
 
 
-@pytest.mark.parametrize("k", [8, 12, 16, 17, 21, 24])
+@pytest.mark.parametrize("k", [2, 3, 4, 8, 12, 16, 17, 21, 24])
 def test_one_walk_kernel_side_roads(hip, oracle, k):
-    """Lists of 8 to 24 neighbours go through the kernel whose insertion chain carries truncated
+    """Lists of 2 to 24 neighbours go through the kernel whose insertion chain carries truncated
     distance keys: pairs it has to re-order by the full keys, runs and crowded cubes it hands
     over must all end in the oracle's lists, bit for bit."""
     x, y, z = _tie_and_crowd_cloud()

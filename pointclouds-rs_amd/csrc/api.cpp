@@ -751,11 +751,11 @@ int pcrs_ransac_plane_samples(pcrs_ctx *ctx, const float *x, const float *y, con
     if (n_samples)
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(dsamp.p, samples, 3 * n_samples * sizeof(uint32_t),
                                            hipMemcpyHostToDevice, ctx->stream));
+    // the mask travels back inside the call's own wait for its results
     PCRS_TRY(pcrs_launch_ransac_plane(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(), n,
                                       dsamp.as<uint32_t>(), n_samples, distance_threshold, model,
-                                      dmask.as<uint8_t>(), n_inliers, best_count));
-    if (n) PCRS_TRY(download(ctx, inlier_mask, dmask.p, n));
-    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                                      dmask.as<uint8_t>(), n_inliers, best_count,
+                                      n ? inlier_mask : nullptr));
     return PCRS_OK;
 } catch (...) {
     return pcrs_on_exception(ctx);

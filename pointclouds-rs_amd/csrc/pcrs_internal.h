@@ -258,11 +258,13 @@ int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, 
                                  size_t n, float voxel_size, float *ox, float *oy, float *oz,
                                  size_t *n_out);
 // Plane RANSAC behind its sample generation (ransac.hip): d_samples holds ns index triples,
-// d_mask receives the inlier mask of the chosen plane.
+// d_mask receives the inlier mask of the chosen plane.  The call waits for the stream (its results
+// are host values); h_mask_out (nullable, host memory) receives a copy of the mask before that
+// wait, so that a caller with host buffers does not wait a second time.
 int pcrs_launch_ransac_plane(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                              size_t n, const uint32_t *d_samples, size_t ns, float thr,
                              float model_out[4], uint8_t *d_mask, size_t *n_inliers,
-                             uint64_t *best_count_out);
+                             uint64_t *best_count_out, uint8_t *h_mask_out = nullptr);
 // euclidean_cluster on device columns (cluster.hip): CSR output, d_offsets holds up to n + 1
 // entries and d_indices up to n.
 int pcrs_launch_euclidean_cluster(pcrs_ctx *ctx, const float *x, const float *y, const float *z,

@@ -78,6 +78,76 @@ __global__ __launch_bounds__(256) void plane_count_kernel(const float *x, const 
     if (s < ns && f.valid && c) atomicAdd(&counts[s], (unsigned long long)c);
 }
 
+// What the search over the samples settles on: the plane, its inlier count, and the number of
+// inliers the mask pass finds for it (the same number, unless no sample was valid).
+struct PlanePick {
+    PlaneFit best;
+    uint32_t pad;
+    unsigned long long count;
+    unsigned long long inliers;
+};
+
+// ransac_plane.rs:83-94 on the device: reduce_with(|a, b| if a.1 >= b.1 { a } else { b }) over the
+// valid samples keeps the earliest of the planes with the largest count; nothing valid -> the
+// default model with count 0.  One block; also clears the inlier total for the mask pass.
+__global__ __launch_bounds__(256) void plane_pick_kernel(const PlaneFit *fits,
+                                                         const unsigned long long *counts,
+                                                         uint32_t ns, PlanePick *pick) {
+    __shared__ unsigned long long s_count[256];
+    __shared__ uint32_t s_at[256];
+    unsigned long long c = 0;
+    uint32_t at = 0xFFFFFFFFu;  // no valid sample yet
+    for (uint32_t s = threadIdx.x; s < ns; s += 256) {
+        if (!fits[s].valid) continue;
+        if (at == 0xFFFFFFFFu || counts[s] > c) {  // ascending s: an equal count keeps the earlier
+            c = counts[s];
+            at = s;
+        }
+    }
+    s_count[threadIdx.x] = c;
+    s_at[threadIdx.x] = at;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const unsigned long long oc = s_count[threadIdx.x + w];
+            const uint32_t oa = s_at[threadIdx.x + w];
+            const uint32_t ma = s_at[threadIdx.x];
+            const bool take = oa != 0xFFFFFFFFu &&
+                              (ma == 0xFFFFFFFFu || oc > s_count[threadIdx.x] ||
+                               (oc == s_count[threadIdx.x] && oa < ma));
+            if (take) {
+                s_count[threadIdx.x] = oc;
+                s_at[threadIdx.x] = oa;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t b = s_at[0];
+        PlanePick p;
+        p.best = b != 0xFFFFFFFFu ? fits[b] : PlaneFit{0.0f, 0.0f, 1.0f, 0.0f, 1u};
+        p.pad = 0;
+        p.count = b != 0xFFFFFFFFu ? s_count[0] : 0ull;
+        p.inliers = 0;
+        *pick = p;
+    }
+}
+
+__global__ __launch_bounds__(256) void plane_mask_pick_kernel(const float *x, const float *y,
+                                                              const float *z, size_t n,
+                                                              PlanePick *pick, float thr,
+                                                              uint8_t *mask) {
+    const PlaneFit f = pick->best;
+    unsigned local = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float dist = fabsf(((f.nx * x[i] + f.ny * y[i]) + f.nz * z[i]) + f.d);
+        const bool in = dist <= thr;
+        mask[i] = in ? 1 : 0;
+        local += in ? 1u : 0u;
+    }
+    block_count_add(local, &pick->inliers);
+}
+
 __global__ __launch_bounds__(256) void plane_mask_kernel(const float *x, const float *y,
                                                          const float *z, size_t n, PlaneFit f,
                                                          float thr, uint8_t *mask,
@@ -99,7 +169,7 @@ using namespace pcrs;
 int pcrs_launch_ransac_plane(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                              size_t n, const uint32_t *d_samples, size_t ns, float thr,
                              float model_out[4], uint8_t *d_mask, size_t *n_inliers,
-                             uint64_t *best_count_out) {
+                             uint64_t *best_count_out, uint8_t *h_mask_out) {
     model_out[0] = 0.0f;  // PlaneModel::default (:23-30)
     model_out[1] = 0.0f;
     model_out[2] = 1.0f;
@@ -110,6 +180,10 @@ int pcrs_launch_ransac_plane(pcrs_ctx *ctx, const float *x, const float *y, cons
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "cloud or sample list too long");
     if (n < 3) {  // :64-66
         if (n) PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_mask, 0, n, ctx->stream));
+        if (n && h_mask_out) {
+            PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_mask_out, d_mask, n, hipMemcpyDeviceToHost, ctx->stream));
+            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        }
         return PCRS_OK;
     }
     PlaneFit best = {0.0f, 0.0f, 1.0f, 0.0f, 1u};
@@ -135,6 +209,38 @@ int pcrs_launch_ransac_plane(pcrs_ctx *ctx, const float *x, const float *y, cons
                            ctx->stream, x, y, z, (uint32_t)n, (uint32_t)slice, fits.as<PlaneFit>(),
                            (uint32_t)ns, thr, counts.as<unsigned long long>());
         PCRS_HIP_CHECK(ctx, hipGetLastError());
+        if (n >= 10000 && ns >= 16) {  // :81, the parallel branch
+            // The choice among the samples is a reduction with a fixed rule: it stays on the
+            // device, the mask pass reads the chosen plane from memory, and the host waits once --
+            // for the plane, its count and the inlier total, which kernels leave in pinned memory
+            // -- instead of three times with two pageable copies of the per-sample results.
+            void *pin = nullptr, *sc = nullptr;
+            PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &pin));
+            PCRS_TRY(pcrs_ctx_scratch(ctx, 64, &sc));
+            static_assert(sizeof(PlanePick) <= 64 && sizeof(PlanePick) % 4 == 0, "fits the scratch words");
+            PlanePick *dpick = reinterpret_cast<PlanePick *>(sc);
+            hipLaunchKernelGGL(plane_pick_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                               fits.as<PlaneFit>(), counts.as<unsigned long long>(), (uint32_t)ns,
+                               dpick);
+            size_t mblocks = (n + 1023) / 1024;
+            if (mblocks > (size_t)ctx->num_cus * 2) mblocks = (size_t)ctx->num_cus * 2;
+            hipLaunchKernelGGL(plane_mask_pick_kernel, dim3((unsigned)mblocks), dim3(256), 0,
+                               ctx->stream, x, y, z, n, dpick, thr, d_mask);
+            PCRS_HIP_CHECK(ctx, hipGetLastError());
+            PCRS_TRY(pcrs_launch_publish(ctx, dpick, pin, sizeof(PlanePick)));
+            if (h_mask_out)
+                PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_mask_out, d_mask, n, hipMemcpyDeviceToHost,
+                                                   ctx->stream));
+            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const PlanePick *hp = reinterpret_cast<const PlanePick *>(pin);
+            model_out[0] = hp->best.nx;
+            model_out[1] = hp->best.ny;
+            model_out[2] = hp->best.nz;
+            model_out[3] = hp->best.d;
+            if (best_count_out) *best_count_out = hp->count;
+            *n_inliers = (size_t)hp->inliers;
+            return PCRS_OK;
+        }
         std::vector<PlaneFit> hf(ns);
         std::vector<unsigned long long> hc(ns);
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hf.data(), fits.p, ns * sizeof(PlaneFit),
@@ -190,6 +296,8 @@ int pcrs_launch_ransac_plane(pcrs_ctx *ctx, const float *x, const float *y, cons
                        n, best, thr, d_mask, dtotal);
     PCRS_HIP_CHECK(ctx, hipMemcpyAsync(htotal, dtotal, sizeof(*htotal), hipMemcpyDeviceToHost,
                                        ctx->stream));
+    if (h_mask_out)
+        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(h_mask_out, d_mask, n, hipMemcpyDeviceToHost, ctx->stream));
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *n_inliers = (size_t)*htotal;
     return PCRS_OK;

@@ -251,13 +251,8 @@ class PlaneResult:
         return "PlaneResult(normal=%r, d=%.4f, inliers=%d)" % (self.normal, self.d, len(self.inliers))
 
 
-def sample_triples(n, iterations, seed):
-    """The sampling procedure of ransac_plane.rs:141-165 (three distinct indices, up to 100 retries
-    each) over a SplitMix64 stream.  The reference draws from rand's StdRng (ChaCha12), which
-    cannot be reproduced without that crate: a Rust caller passes its own triples to
-    pcrs_ransac_plane_samples, this generator only serves the Python mirror."""
-    if n < 3:
-        return np.zeros((0, 3), dtype=np.uint32)
+def _sample_triples_scalar(n, iterations, seed):
+    """sample_triples, draw by draw (the definition; the vectorised road must equal it)."""
     mask = (1 << 64) - 1
     state = [int(seed) & mask]
 
@@ -288,6 +283,36 @@ def sample_triples(n, iterations, seed):
             continue
         out.append((i0, i1, i2))
     return np.array(out, dtype=np.uint32).reshape(-1, 3)
+
+
+def sample_triples(n, iterations, seed):
+    """The sampling procedure of ransac_plane.rs:141-165 (three distinct indices, up to 100 retries
+    each) over a SplitMix64 stream.  The reference draws from rand's StdRng (ChaCha12), which
+    cannot be reproduced without that crate: a Rust caller passes its own triples to
+    pcrs_ransac_plane_samples, this generator only serves the Python mirror.
+
+    SplitMix64 is a function of the draw counter, so all draws of a call are computed at once;
+    when no triple needs a redraw (nearly always, on clouds of thousands of points) the triples
+    are those draws three by three, otherwise the call takes the draw-by-draw road."""
+    iterations = int(iterations)
+    if n < 3:
+        return np.zeros((0, 3), dtype=np.uint32)
+    if iterations <= 0 or n >= (1 << 32):
+        return _sample_triples_scalar(n, iterations, seed)
+    with np.errstate(over="ignore"):
+        k = np.arange(1, 3 * iterations + 1, dtype=np.uint64)
+        v = np.uint64(int(seed) & ((1 << 64) - 1)) + k * np.uint64(0x9E3779B97F4A7C15)
+        v = (v ^ (v >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        v = (v ^ (v >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        v ^= v >> np.uint64(31)
+        # (v * n) >> 64 for n < 2^32, in 64-bit pieces
+        m = np.uint64(n)
+        hi = (v >> np.uint64(32)) * m
+        lo = ((v & np.uint64(0xFFFFFFFF)) * m) >> np.uint64(32)
+        t = ((hi + lo) >> np.uint64(32)).reshape(iterations, 3)
+    if ((t[:, 0] != t[:, 1]) & (t[:, 2] != t[:, 0]) & (t[:, 2] != t[:, 1])).all():
+        return t.astype(np.uint32)
+    return _sample_triples_scalar(n, iterations, seed)
 
 
 def ransac_plane_seeded(cloud, distance_threshold, iterations, seed):

@@ -87,3 +87,16 @@ def test_argument_validation_matches_reference():
 def test_out_of_scope_functions_are_absent():
     for name in ("passthrough_filter",):
         assert not hasattr(pc, name)
+
+
+def test_sample_triples_vectorised_road_equals_the_definition():
+    """All draws at once (SplitMix64 is a function of the draw counter) must give the triples of
+    the draw-by-draw procedure, whether or not a redraw happens."""
+    import pointclouds_rs as pc
+
+    for n, it, seed in [(45000, 500, 1234), (100000, 1000, 1), (3, 50, 9), (10, 200, 77),
+                        (5000, 2000, 2 ** 63 + 12345), (4_000_000_000, 100, 5), (70000, 0, 3),
+                        (2, 10, 1)]:
+        a = pc.sample_triples(n, it, seed)
+        b = pc._sample_triples_scalar(n, it, seed) if n >= 3 else np.zeros((0, 3), np.uint32)
+        assert a.dtype == np.uint32 and a.shape == b.shape and np.array_equal(a, b), (n, it, seed)

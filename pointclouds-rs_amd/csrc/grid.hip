@@ -2285,6 +2285,20 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     // a radius search wants cells of the radius (one attempt, no occupancy feedback)
     const bool fixed_cell = cell_request > 0.0f && cell_request < 1e30f;
     if (fixed_cell) cell = (double)cell_request;
+    // a cloud like the one before it (same list length, size and extent within 30 %) starts from
+    // the cell that one ended with, scaled by the change in density a surface would show
+    static const bool use_hint = [] {  // experiments only: PCRS_GRID_HINT=0
+        const char *e = getenv("PCRS_GRID_HINT");
+        return !(e && e[0] == '0');
+    }();
+    const pcrs_ctx::GridHint &gh = ctx->grid_hint;
+    bool hinted = false;
+    if (use_hint && !fixed_cell && gh.cell > 0.0 && gh.k_hint == k_hint &&
+        (double)nvalid > 0.7 * (double)gh.n && (double)nvalid < 1.3 * (double)gh.n &&
+        emax > 0.7 * gh.emax && emax < 1.3 * gh.emax) {
+        cell = gh.cell * pow((double)gh.n / (double)nvalid, 1.0 / gh.dim);
+        hinted = true;
+    }
     // cell budget: 4 cells per point; experiments may override the factor
     double cells_per_point = 4.0;
     if (const char *e = getenv("PCRS_GRID_CELLS_PER_POINT")) {
@@ -2310,7 +2324,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     const bool dim_aware = dim_switch && k_hint >= 8 && !getenv("PCRS_GRID_OCC");
     double P_surface = 0.75 * (double)k_hint;
     P_surface = P_surface < P ? P : (P_surface > 64.0 ? 64.0 : P_surface);
-    double dim = 3.0, prev_cell = 0.0, prev_occ = 0.0;
+    double dim = hinted ? gh.dim : 3.0, prev_cell = 0.0, prev_occ = 0.0;
     for (int attempt = 0;; ++attempt) {
         double used = cell;
         make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
@@ -2382,15 +2396,18 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
                 (prev_cell >= 1.25 * cell || cell >= 1.25 * prev_cell)) {
                 dim = log(prev_occ / occ) / log(prev_cell / cell);
                 dim = dim < 2.0 ? 2.0 : (dim > 3.0 ? 3.0 : dim);
-            } else if (attempt == 0) {
-                dim = std::min(g.nx, std::min(g.ny, g.nz)) <= 2 ? 2.0 : 3.0;
+            } else if (attempt == 0 && !hinted) {
+                // nothing to compare with yet: a grid one or two cells thick, or one whose points
+                // leave two thirds of the cells empty, is taken for a surface
+                const bool thin = std::min(g.nx, std::min(g.ny, g.nz)) <= 2;
+                dim = thin || (double)nonempty < 0.35 * (double)ncell ? 2.0 : 3.0;
             }
             prev_cell = cell;
             prev_occ = occ;
             const double aim = P + (3.0 - dim) * (P_surface - P);
             if (occ >= 0.75 * aim && occ <= 1.6 * aim) break;
             double f = pow(aim / occ, 1.0 / dim);
-            f = f < 0.4 ? 0.4 : (f > 2.5 ? 2.5 : f);
+            f = f < 0.2 ? 0.2 : (f > 2.5 ? 2.5 : f);
             next = cell * f;
         } else {
             if (occ <= 1.6 * P) break;
@@ -2457,6 +2474,13 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     counts.owner = nullptr;
     ix->g = g;
     ix->ncell = ncell;
+    if (!fixed_cell) {
+        ctx->grid_hint.cell = cell;
+        ctx->grid_hint.emax = emax;
+        ctx->grid_hint.dim = dim;
+        ctx->grid_hint.n = nvalid;
+        ctx->grid_hint.k_hint = k_hint;
+    }
     ix->algo = PCRS_ALGO_GRID;
     return PCRS_OK;
 }

@@ -49,6 +49,15 @@ struct pcrs_ctx {
         size_t bytes;
     };
     std::vector<PoolEntry> pool;
+    // The grid geometry the last index build settled on (grid.hip): a caller that feeds one cloud
+    // after another of the same kind -- frames of a sensor -- starts the next build from it and
+    // usually needs one sizing attempt instead of three.  Only a starting point: every build
+    // still checks the occupancy it gets.
+    struct GridHint {
+        double cell = 0.0, emax = 0.0, dim = 3.0;
+        size_t n = 0;
+        uint32_t k_hint = 0;
+    } grid_hint;
 };
 
 hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap);

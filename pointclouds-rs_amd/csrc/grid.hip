@@ -141,10 +141,17 @@ constexpr uint32_t SCAN_SMALL_MAX = 32768;
 __global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *data, uint32_t n,
                                                           uint32_t *total_out) {
     __shared__ uint32_t wsum[16];
-    const uint32_t per = (n + 1023u) / 1024u;  // <= 32
+    constexpr int PER_MAX = SCAN_SMALL_MAX / 1024;
+    const uint32_t per = (n + 1023u) / 1024u;  // <= PER_MAX
     const uint32_t b = threadIdx.x * per;
+    // a thread's items in registers, every load requested before the first is used (one block
+    // has nothing else to hide a chain of dependent loads behind: 17 items took 17 round trips)
+    uint32_t v[PER_MAX];
+#pragma unroll
+    for (int i = 0; i < PER_MAX; ++i) v[i] = ((uint32_t)i < per && b + i < n) ? data[b + i] : 0u;
     uint32_t t = 0;
-    for (uint32_t i = 0; i < per; ++i) t += (b + i < n) ? data[b + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < PER_MAX; ++i) t += v[i];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = t;
     for (int off = 1; off < 64; off <<= 1) {
@@ -155,12 +162,10 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *data, uint32
     __syncthreads();
     uint32_t run = incl - t;
     for (int w = 0; w < wave; ++w) run += wsum[w];
-    for (uint32_t i = 0; i < per; ++i) {
-        if (b + i < n) {
-            const uint32_t v = data[b + i];
-            data[b + i] = run;
-            run += v;
-        }
+#pragma unroll
+    for (int i = 0; i < PER_MAX; ++i) {
+        if ((uint32_t)i < per && b + i < n) data[b + i] = run;
+        run += v[i];
     }
     if (threadIdx.x == 1023 && total_out) *total_out = run;
 }

@@ -2298,7 +2298,10 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     }();
     const pcrs_ctx::GridHint &gh = ctx->grid_hint;
     bool hinted = false;
-    if (use_hint && !fixed_cell && gh.cell > 0.0 && gh.k_hint == k_hint &&
+    // (Only for clouds that arrive in host memory: the ranks of a sharded run build their indices
+    // over device columns and must all derive the same geometry from the cloud alone, whatever
+    // each of them has built before.)
+    if (use_hint && ix->own_x.p && !fixed_cell && gh.cell > 0.0 && gh.k_hint == k_hint &&
         (double)nvalid > 0.7 * (double)gh.n && (double)nvalid < 1.3 * (double)gh.n &&
         emax > 0.7 * gh.emax && emax < 1.3 * gh.emax) {
         cell = gh.cell * pow((double)gh.n / (double)nvalid, 1.0 / gh.dim);

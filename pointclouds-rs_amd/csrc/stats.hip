@@ -472,12 +472,16 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
             scomp[i] = c;
         }
         if (tid < 64u) pre_chunk[tid] = 0xFFFFFFFFu;
+        if (tid == 0) npre_s = 0u;
         __syncthreads();
-        if (tid < 64u) {
-            uint32_t np = 0;
-            const unsigned long long lt = (1ull << tid) - 1ull;
-            for (uint32_t b0 = 0; b0 < nloc; b0 += 64u) {
-                const uint32_t c = b0 + tid;
+        {
+            // every wave of the block looks at its share of the chunks (which of the predicted
+            // chunks get a place when there are more than ST_PRE of them does not matter: a chunk
+            // that was not fetched ahead is read when the walk reaches it)
+            const uint32_t ln = tid & 63u;
+            const unsigned long long lt = (1ull << ln) - 1ull;
+            for (uint32_t b0 = (tid >> 6) * 64u; b0 < nloc; b0 += nth) {
+                const uint32_t c = b0 + ln;
                 bool cross = false;
                 if (c < nloc) {
                     // a crossing inside chunk c, or inside a neighbour (the f32 sum drifts off the
@@ -487,16 +491,19 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
                     cross = e0 != e1 || e0 == ST_NO_BINADE;
                 }
                 const unsigned long long m = __ballot(cross);
-                if (cross) {
-                    const uint32_t at = np + (uint32_t)__popcll(m & lt);
-                    if (at < (uint32_t)ST_PRE) pre_chunk[at] = chunk_begin + c;
+                if (m) {
+                    uint32_t first = 0;
+                    if (ln == 0) first = atomicAdd(&npre_s, (uint32_t)__popcll(m));
+                    first = __shfl(first, 0, 64);
+                    if (cross) {
+                        const uint32_t at = first + (uint32_t)__popcll(m & lt);
+                        if (at < (uint32_t)ST_PRE) pre_chunk[at] = chunk_begin + c;
+                    }
                 }
-                np += (uint32_t)__popcll(m);
             }
-            if (tid == 0) npre_s = np < (uint32_t)ST_PRE ? np : (uint32_t)ST_PRE;
         }
         __syncthreads();
-        const uint32_t npre = npre_s;
+        const uint32_t npre = npre_s < (uint32_t)ST_PRE ? npre_s : (uint32_t)ST_PRE;
         for (uint32_t t = tid; t < npre * 64u; t += nth) {
             const uint32_t p = t >> 6, l = t & 63u;
             bool fin;

@@ -240,6 +240,13 @@ def run_sor_normals(args):
     nq = int(res["mean"].numel())  # queries this rank answered per step
     achieved = BYTES_PER_POINT * nq / avg_kernel_s / 1e9 if launches else 0.0
 
+    # Side lines on one GPU: the SOR stage alone (the stage north_star's target is quoted on) and
+    # the same step with nothing left in the caches from the step before.
+    sor_only_line = cold_line = None
+    if world == 1 and not c4 and not args.no_stages:
+        sor_only_line = bench_sor_only(engine, coll, shard, n_total, vp, outputs, args)
+        cold_line = bench_cold(engine, step, args)
+
     icp_line = stages_line = host_line = None
     if not c4 and rank == 0:
         if args.icp_iters > 0:
@@ -294,6 +301,10 @@ def run_sor_normals(args):
         # the committed counter passes were taken on the default workload (1 M points per GPU)
         if not c4 and n_total // world == POINTS_PER_GPU:
             out["roofline"].update(profile_counters(avg_kernel_s))
+        if sor_only_line:
+            out["sor_only"] = sor_only_line
+        if cold_line:
+            out["cold"] = cold_line
         if icp_line:
             out["icp"] = icp_line
         if stages_line:
@@ -306,6 +317,67 @@ def run_sor_normals(args):
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def bench_sor_only(engine, coll, shard, n_total, vp, outputs, args):
+    """statistical_outlier_removal alone (no normals) on the same resident cloud: index build,
+    search for distances only (knn_cell_kernel<17,false>: one walk, no neighbour identities),
+    statistics, mask.  17 algorithmic bytes per point (12 read, 4 mean, 1 mask)."""
+    import torch
+
+    from pointclouds_rs.dist import sor_normals_sharded
+
+    def step():
+        return sor_normals_sharded(engine, coll, shard, n_total, K_SOR, STD_MUL, 0, vp, outputs)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    engine.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = engine.timing_read()
+    engine.timing(False)
+    ksec = kernel_ms / max(launches, 1) * 1e-3
+    gbps = 17 * n_total / ksec / 1e9 if launches else 0.0
+    return {"workload": f"SOR k={K_SOR} std_mul={STD_MUL} alone, {n_total} points",
+            "ms_per_step": dt / args.steps * 1e3, "Mpoints_per_s": n_total * args.steps / dt / 1e6,
+            "n_keep": int(res["n_keep"]), "kernel": "knn_cell_kernel<17,false>",
+            "kernel_ms_avg": ksec * 1e3, "algorithmic_bytes_per_launch": 17 * n_total,
+            "achieved_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS}
+
+
+def bench_cold(engine, step, args, scrub_bytes=1 << 30):
+    """The default step with cold caches: between two steps a 1 GiB buffer is rewritten (four
+    times the 256 MB of memory-side cache, far beyond the L2s), so the cloud, the index and every
+    intermediate of the step before are gone and the step's reads come from HBM.  Each step is
+    timed on its own with events on the stream the library runs on; the scrub is not timed."""
+    import torch
+
+    scrub = torch.empty(scrub_bytes // 4, dtype=torch.float32, device=engine.device)
+    steps = min(args.steps, 10)
+    engine.timing(True)
+    pairs = []
+    for i in range(steps + 1):
+        scrub.fill_(float(i))
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    kernel_ms, launches = engine.timing_read()
+    engine.timing(False)
+    ms = sorted(a.elapsed_time(b) for a, b in pairs[1:])
+    del scrub
+    return {"method": "1 GiB rewritten between steps (untimed); each step timed by events on its stream",
+            "steps": steps, "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0],
+            "ms_per_step_max": ms[-1], "kernel_ms_avg": kernel_ms / max(launches, 1),
+            "Mpoints_per_s": POINTS_PER_GPU / (ms[len(ms) // 2] * 1e-3) / 1e6}
 
 
 def profile_counters(avg_kernel_s):

@@ -124,7 +124,9 @@ int pcrs_radius_count_dev(pcrs_index *index, const float *dqx, const float *dqy,
  * ascending index order (kdtree.rs:131-132); offsets[n+1].  *total receives the number of
  * results.  When they do not fit `capacity` (or indices is NULL) the call returns
  * PCRS_ERR_INVALID_ARG with offsets and *total filled in, so that the caller can size the list
- * and call again; more than 2^32-2 results in one call are refused the same way. */
+ * and call again.  More than 2^32-2 results in one call are refused with the same code: *total
+ * still holds their number, but 32-bit offsets cannot describe them and are all zero then (search
+ * fewer queries at a time). */
 int pcrs_radius_search(pcrs_index *index, const float *qx, const float *qy, const float *qz,
                        size_t n, float radius, uint32_t *offsets, uint32_t *indices,
                        size_t capacity, size_t *total);

@@ -601,9 +601,12 @@ int pcrs_radius_search_dev(pcrs_index *index, const float *dqx, const float *dqy
     PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const unsigned long long t = *reinterpret_cast<unsigned long long *>(pin);
     *total = (size_t)t;
-    if (t >= 0xFFFFFFFFull)
+    if (t >= 0xFFFFFFFFull) {
+        // the 32-bit scan has wrapped: the caller gets zeros rather than offsets that mean nothing
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(doffsets, 0, (n + 1) * sizeof(uint32_t), ctx->stream));
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG,
                             "%llu results do not fit 32-bit offsets: search fewer queries at a time", t);
+    }
     if (t == 0) return PCRS_OK;
     if (t > capacity || !dindices)
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG,
@@ -615,11 +618,9 @@ int pcrs_radius_search_dev(pcrs_index *index, const float *dqx, const float *dqy
         int idx_bits = 1, q_bits = 1;
         while (idx_bits < 32 && (index->m >> idx_bits)) ++idx_bits;
         while (q_bits < 32 && (n >> q_bits)) ++q_bits;
-        DevBuf keys, keys_alt, vals, vals_alt;
+        DevBuf keys, keys_alt;  // the key carries the index: a keys-only sort, 16 B per result
         PCRS_HIP_CHECK(ctx, keys.alloc(ctx, t * sizeof(uint64_t)));
         PCRS_HIP_CHECK(ctx, keys_alt.alloc(ctx, t * sizeof(uint64_t)));
-        PCRS_HIP_CHECK(ctx, vals.alloc(ctx, t * sizeof(uint32_t)));
-        PCRS_HIP_CHECK(ctx, vals_alt.alloc(ctx, t * sizeof(uint32_t)));
         KnnQuery q;
         q.qx = dqx;
         q.qy = dqy;
@@ -628,9 +629,8 @@ int pcrs_radius_search_dev(pcrs_index *index, const float *dqx, const float *dqy
         PCRS_TRY(pcrs_launch_radius_fill_grid(index, q, radius, doffsets, keys.as<uint64_t>(),
                                               idx_bits));
         bool in_alt = false;
-        PCRS_TRY(pcrs_sort_pairs_u64(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(),
-                                     keys_alt.as<uint64_t>(), vals_alt.as<uint32_t>(), (size_t)t,
-                                     idx_bits + q_bits, &in_alt));
+        PCRS_TRY(pcrs_sort_pairs_u64(ctx, keys.as<uint64_t>(), nullptr, keys_alt.as<uint64_t>(),
+                                     nullptr, (size_t)t, idx_bits + q_bits, &in_alt));
         PCRS_TRY(pcrs_launch_key_low_bits(ctx, in_alt ? keys_alt.as<uint64_t>() : keys.as<uint64_t>(),
                                           (size_t)t, idx_bits, dindices));
         return PCRS_OK;

@@ -2695,7 +2695,8 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     // search before it, or just now), and its first kernel clears the other set
     uint32_t *counters = ix->counters.as<uint32_t>() + 16 * ix->counter_phase;
     uint32_t *counters_next = ix->counters.as<uint32_t>() + 16 * (ix->counter_phase ^ 1);
-    ix->counter_phase ^= 1;
+    // (the phase flips once the first stage, which clears the other set, has been queued: a call
+    // that fails before then must leave the next search on this still-clean set)
 
     CellArgs a{};
     a.g = ix->g;
@@ -2881,6 +2882,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     pcrs_timing_begin(ctx);
     launch(blocks1);
     pcrs_timing_end(ctx);
+    ix->counter_phase ^= 1;
     a.xform = nullptr;
     a.zero_me = nullptr;
     a.alt_list = nullptr;

@@ -246,6 +246,7 @@ int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums
                          uint32_t *total_out);
 // Stable LSD radix sort of (u64 key, u32 value) pairs on the low key_bits bits of the key
 // (sort.hip).  Both buffer pairs are used; *in_alt tells whether the result is in the alt pair.
+// vals and vals_alt may both be null: the keys are then sorted alone.
 int pcrs_sort_pairs_u64(pcrs_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt,
                         uint32_t *vals_alt, size_t n, int key_bits, bool *in_alt);
 // Points ordered by an integer cell key per axis (voxel.hip): key = floor(p / scale) or

@@ -1,4 +1,5 @@
-// Stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, for the paths that order
+// Stable LSD radix sort of (u64 key, u32 value) pairs (or of keys alone: null value arrays), 8 bits
+// per pass, for the paths that order
 // points by a sparse integer key (voxel ids, cluster labels).  One wave owns a contiguous chunk of
 // 1024 pairs in both kernels of a pass, so ranks inside a chunk need no block barrier:
 //   histogram : per-chunk digit counts (LDS atomics) into a digit-major table [256][chunks]
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64) void radix_scatter_kernel(const uint64_t *keys,
         uint32_t val = 0;
         if (live) {
             key = keys[i];
-            val = vals[i];
+            if (vals) val = vals[i];  // keys only: no values to carry
         }
         const uint32_t digit = (uint32_t)(key >> shift) & 255u;
         // lanes with the same digit (dead lanes match nobody)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64) void radix_scatter_kernel(const uint64_t *keys,
             const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
             const uint32_t at = first_slot + rank;
             keys_out[at] = key;
-            vals_out[at] = val;
+            if (vals) vals_out[at] = val;
             if (rank == 0) cursor[digit] = first_slot + (uint32_t)__popcll(peers);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

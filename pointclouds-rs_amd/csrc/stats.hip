@@ -437,6 +437,13 @@ constexpr uint32_t ST_STAGE_CHUNKS = 4096;
 constexpr int ST_PRE = 48;  // chunks whose elements are fetched ahead
 
 constexpr int ST_STAGE_THREADS = 1024;
+// The staged walker keeps all of this in LDS at once: it is sized for the 160 KB of a gfx950
+// compute unit (the 64 KB of earlier gfx9 parts cannot hold it; a build for one of those must
+// lower ST_STAGE_CHUNKS, which only moves more sums to the unstaged walker).
+static_assert(ST_STAGE_CHUNKS * sizeof(Composite) + (size_t)ST_PRE * 64 * sizeof(float4) +
+                      64 * sizeof(float4) + 64 * sizeof(uint32_t) + 64 <=
+                  160 * 1024,
+              "staged statistics walker exceeds the LDS of a gfx950 compute unit");
 
 template <int PASS, int W, bool STAGE>
 __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kernel(const float *mean, size_t n,

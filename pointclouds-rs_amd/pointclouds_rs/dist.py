@@ -55,6 +55,31 @@ class HipEngine:
             self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.lib = self.ctx.lib
 
+    _shared = {}
+
+    @classmethod
+    def shared(cls, device_index: int = 0):
+        """One engine per device for callers that create engines over and over (test suites,
+        drivers): every engine owns a context with its own pooled device memory, and two engines
+        on one GPU would also share the static work space of pcrs_sor_select_static_dev."""
+        eng = cls._shared.get(device_index)
+        if eng is None or eng.ctx is None:
+            eng = cls._shared[device_index] = cls(device_index)
+        return eng
+
+    def close(self):
+        """Releases the engine's context (stream binding, pinned block, pooled device memory)."""
+        ctx, self.ctx = self.ctx, None
+        if ctx is not None:
+            ctx.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # -- tensors
     def empty(self, n, dtype="float32"):
         return self.torch.empty(n, dtype=getattr(self.torch, dtype), device=self.device)
@@ -282,19 +307,6 @@ class Collectives:
                 t.copy_(h)
             else:
                 self.dist.all_reduce(t)
-
-    def all_reduce_sum_f64(self, torch, arr, device):
-        """Sums a small float64 NumPy vector over ranks (rank-order independent result)."""
-        if self.world == 1:
-            return arr
-        # gather then add in rank order, so every rank obtains bit-identical sums
-        t = torch.from_numpy(arr.copy()).to("cpu" if self.stage else device)
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t)
-        acc = np.zeros_like(arr)
-        for o in outs:
-            acc = acc + o.cpu().numpy()
-        return acc
 
     def barrier(self):
         if self.dist:

@@ -42,7 +42,7 @@ def _worker(rank, world, port, q, icp_inputs):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    eng = HipEngine(0)
+    eng = HipEngine.shared(0)
     coll = Collectives(dist, stage_through_host=True)  # gloo has no device collectives here
     x, y, z = _cloud()
     n_total = len(x)

@@ -123,7 +123,7 @@ def test_random_clouds_runs_of_cells(kind, seed):
     equals the answer of the index-range entry point for the point it names, bit for bit."""
     from pointclouds_rs.dist import HipEngine
 
-    eng = HipEngine(0)
+    eng = HipEngine.shared(0)
     torch = eng.torch
     rng = np.random.default_rng(7000 + 100 * KINDS.index(kind) + seed)
     n = int(rng.choice([64, 100, 1000, 5000, 9000]))

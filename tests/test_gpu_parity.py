@@ -618,7 +618,7 @@ def test_query_subrange_equals_full(oracle):
     multi-GPU path) must give exactly the rows of the full-range result."""
     from pointclouds_rs.dist import HipEngine
 
-    eng = HipEngine(0)
+    eng = HipEngine.shared(0)
     x, y, z = gen.degenerate_cloud(300, 7)
     ux, uy, uz = gen.uniform_cloud(30000, 11)
     x, y, z = np.concatenate([x, ux]), np.concatenate([y, uy]), np.concatenate([z, uz])
@@ -658,7 +658,7 @@ def test_slot_runs_equal_full(oracle):
     points it names (means bit for bit, normals within tolerance)."""
     from pointclouds_rs.dist import HipEngine
 
-    eng = HipEngine(0)
+    eng = HipEngine.shared(0)
     torch = eng.torch
     dx, dy, dz = (np.nan_to_num(c, nan=1.5, posinf=2.5, neginf=0.5) for c in gen.degenerate_cloud(300, 7))
     kx, ky, kz = gen.kitti_scene(5, 20000, 3000, 500)
@@ -708,7 +708,7 @@ def test_sharded_driver_cells_single_rank(oracle):
     the run, scatter of the means to index order, exact threshold, mask) against the oracle."""
     from pointclouds_rs.dist import Collectives, HipEngine, sor_normals_sharded
 
-    eng = HipEngine(0)
+    eng = HipEngine.shared(0)
     x, y, z = gen.kitti_scene(9, 30000, 4000, 800)
     n = len(x)
     shard = [eng.from_numpy(c) for c in (x, y, z)]
@@ -737,7 +737,7 @@ def test_large_cloud_parity(oracle):
 
     from pointclouds_rs.dist import HipEngine
 
-    eng = HipEngine(0)
+    eng = HipEngine.shared(0)
     n = 6_000_000
     side = np.float32(100.0 * 6 ** (1.0 / 3.0))
     cols_h = [(gen.uniform01(77, n, a) * side).astype(F) for a in range(3)]

@@ -11,7 +11,7 @@ F = np.float32
 def engine():
     from pointclouds_rs.dist import HipEngine
 
-    return HipEngine(0)
+    return HipEngine.shared(0)
 
 
 def cases():

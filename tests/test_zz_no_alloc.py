@@ -39,7 +39,7 @@ def _both(engine, m, b, c, mul):
 def test_static_select_matches_select_twice_in_a_row():
     from pointclouds_rs.dist import HipEngine
 
-    engine = HipEngine(0)
+    engine = HipEngine.shared(0)
     rng = np.random.default_rng(31)
     # first call: past 2^20 means, so the composites are built for four binades (largest layout)
     big = rng.lognormal(0.0, 1.0, 3_000_000).astype(F)
@@ -60,7 +60,7 @@ def test_static_select_rejects_sizes_beyond_its_array():
     from pointclouds_rs import _ffi
     from pointclouds_rs.dist import HipEngine
 
-    engine = HipEngine(0)
+    engine = HipEngine.shared(0)
     n = (1 << 22) + 1
     d = engine.torch.ones(n, dtype=engine.torch.float32, device=engine.device)
     keep = engine.empty(16, "uint8")
@@ -73,3 +73,48 @@ def test_static_select_rejects_sizes_beyond_its_array():
     engine.torch.cuda.synchronize()
     thr, ok, nk = _decode(result)
     assert ok and nk == 16 and thr == 1.0
+
+
+def test_static_select_runs_under_stream_capture():
+    """The property the entry point exists for: it can be recorded into a HIP graph.  A device
+    allocation, a release or a wait for the stream inside the call would invalidate the capture;
+    the replayed graph must then give what pcrs_sor_select_dev gives, twice, the second time on
+    other values in the same buffers."""
+    from pointclouds_rs.dist import HipEngine
+
+    engine = HipEngine(0, use_torch_stream=False)  # a context of its own, bound to a side stream
+    try:
+        torch = engine.torch
+        side = torch.cuda.Stream(device=engine.device)
+        engine.ctx.set_stream(side.cuda_stream)
+        rng = np.random.default_rng(5)
+        n, b, c, mul = 600_000, 1000, 300_000, 1.5
+        host = rng.lognormal(0.0, 0.7, n).astype(F)
+        host[::50021] = np.inf
+        d = engine.from_numpy(host)
+        sub = d[b:b + c]
+        keep = engine.empty(c, "uint8")
+        result = torch.zeros(16, dtype=torch.uint8, device=engine.device)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            engine.select_static(d, mul, sub, keep, result)
+        for rep in range(2):
+            if rep == 1:  # new values in the captured buffers
+                host = rng.uniform(0.1, 4.0, n).astype(F)
+                host[7::9973] = np.nan
+                d.copy_(torch.from_numpy(host))
+            keep.fill_(7)
+            result.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            thr, ok, nk = _decode(result)
+            keep_ref = engine.empty(c, "uint8")
+            thr_ref, ok_ref, nk_ref = engine.select(d, mul, sub, keep_ref)
+            torch.cuda.synchronize()
+            assert ok and ok_ref and nk == nk_ref
+            assert F(thr).view(np.uint32) == F(thr_ref).view(np.uint32), (thr, thr_ref)
+            assert np.array_equal(keep.cpu().numpy(), keep_ref.cpu().numpy())
+    finally:
+        engine.close()

@@ -292,6 +292,54 @@ int pcrs_sor_normals_slots_dev(pcrs_index *index, size_t slot_begin, size_t slot
 int pcrs_scatter_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dpoint, size_t n,
                          float *dout);
 
+/* One cloud over several GPUs by SPACE (no counterpart in the reference; what
+ * pointclouds_rs/dist.py runs with ownership="slabs").  Every process holds the
+ * whole cloud in device columns, but indexes only its own slab of it plus a halo,
+ * and answers the slab's points:
+ *
+ *   pcrs_slab_cuts_dev    cuts the cloud along its longest axis into `parts` slabs of
+ *       nearly equal point counts: slab r = the finite points with cuts[r] <= p[axis]
+ *       < cuts[r + 1] (cuts[0] = -INFINITY, cuts[parts] = +INFINITY; host array of
+ *       parts + 1 floats).  A pure function of the columns: every process derives the
+ *       same cuts without communication.  *halo: how far an index should reach beyond
+ *       its slab so that nearly every neighbourhood of the slab lies inside it;
+ *       *n_finite: finite points of the cloud (points with a non-finite coordinate
+ *       belong to no slab: a cloud that has some is sharded by index ranges instead).
+ *   pcrs_index_build_box_dev   an index over the points with box_lo[a] <= p[a] <
+ *       box_hi[a] only (-INFINITY / +INFINITY: no limit).  The cloud may go on behind a
+ *       limited side of the box, so a search never certifies a result whose ball reaches
+ *       across such a side.  The columns are kept, as by pcrs_index_build_dev.
+ *   pcrs_index_select_box      picks the indexed points inside [q_lo, q_hi) (a part of
+ *       the index's box: the slab without its halo) as the queries of the calls that
+ *       follow; *count = their number.  Fails with PCRS_ERR_INVALID_ARG when the box
+ *       holds too few points for a grid (shard by index ranges then).
+ *   pcrs_sor_normals_selected_dev   the fused search of pcrs_sor_normals_dev over the
+ *       selected points, in cell order: dpoint[i] = index of the i-th of them in the
+ *       columns, dmean / dnx / dny / dnz[i] = its results (either group may be NULL).
+ *       A query whose neighbourhood reaches across a limited side of the box is answered
+ *       from an index over the whole cloud, built inside this index on first need;
+ *       *n_escalated (nullable) = how many took that road.  Waits for the stream once.
+ *   pcrs_slab_index_build_dev   the first three calls in one, for slab `part` of `parts`
+ *       (the cloud is measured once: the index takes its bounds from the cut): the index
+ *       over the slab and its halo with the slab's points selected, *n_queries of them;
+ *       *axis and slab[2] (nullable) = the cut axis and the slab's limits on it.
+ *       *out = NULL with PCRS_OK when the cloud has no slabs: points with a non-finite
+ *       coordinate, no extent, or too few points in this slab for a grid. */
+int pcrs_slab_cuts_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz, size_t m,
+                       uint32_t parts, uint32_t k_hint, int *axis, float *cuts, float *halo,
+                       size_t *n_finite);
+int pcrs_index_build_box_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                             size_t m, uint32_t k_hint, const float box_lo[3],
+                             const float box_hi[3], pcrs_index **out);
+int pcrs_index_select_box(pcrs_index *index, const float q_lo[3], const float q_hi[3],
+                          size_t *count);
+int pcrs_sor_normals_selected_dev(pcrs_index *index, uint32_t k_sor, uint32_t k_normals,
+                                  const float viewpoint[3], uint32_t *dpoint, float *dmean,
+                                  float *dnx, float *dny, float *dnz, size_t *n_escalated);
+int pcrs_slab_index_build_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                              size_t m, uint32_t k_hint, uint32_t parts, uint32_t part,
+                              pcrs_index **out, size_t *n_queries, int *axis, float slab[2]);
+
 /* estimate_normals_with_viewpoint on host buffers.  k == 0 or n == 0 writes
  * nothing (the reference returns empty vectors, estimate.rs:25-31). */
 int pcrs_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,

@@ -161,6 +161,7 @@ int download(pcrs_ctx *ctx, void *dst, const void *src, size_t bytes) {
 int run_query(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed) {
     ix->stats[0] = ix->stats[1] = ix->stats[2] = 0;
     ix->stats_dev = nullptr;
+    ix->left_list = ix->left_count = nullptr;
     if (ix->algo == PCRS_ALGO_GRID) return pcrs_launch_knn_grid(ix, q, out, kneed);
     ix->stats[2] = q.nq;
     q.xform_fused = false;
@@ -933,6 +934,238 @@ int pcrs_sor_normals_slots_dev(pcrs_index *index, size_t slot_begin, size_t slot
         if (k_normals > kneed) kneed = k_normals;
     }
     return run_query(index, q, o, kneed);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
+}
+
+// ---- one cloud over several GPUs by space: slabs, an index per slab (+ halo), the slab's queries
+
+int pcrs_slab_cuts_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz, size_t m,
+                       uint32_t parts, uint32_t k_hint, int *axis, float *cuts, float *halo,
+                       size_t *n_finite) try {
+    PCRS_TRY(bind_device(ctx));
+    if (!axis || !cuts || !halo || !n_finite || parts == 0)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null output or no parts");
+    if (m && (!dx || !dy || !dz)) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    return pcrs_slab_cuts(ctx, dx, dy, dz, m, parts, k_hint, axis, cuts, halo, n_finite);
+} catch (...) {
+    return pcrs_on_exception(ctx);
+}
+
+int pcrs_index_build_box_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                             size_t m, uint32_t k_hint, const float box_lo[3],
+                             const float box_hi[3], pcrs_index **out) try {
+    if (!out) return PCRS_ERR_INVALID_ARG;
+    *out = nullptr;
+    PCRS_TRY(bind_device(ctx));
+    if (!box_lo || !box_hi) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null box");
+    if (m && (!dx || !dy || !dz)) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    for (int a = 0; a < 3; ++a)
+        if (!(box_lo[a] <= box_hi[a]))  // NaN included
+            return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "box with lo > hi on axis %d", a);
+    pcrs_index *ix = new (std::nothrow) pcrs_index();
+    if (!ix) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    ix->ctx = ctx;
+    ix->x = dx;
+    ix->y = dy;
+    ix->z = dz;
+    ix->m = m;
+    for (int a = 0; a < 3; ++a) {
+        ix->box.lo[a] = box_lo[a];
+        ix->box.hi[a] = box_hi[a];
+    }
+    ix->k_hint = k_hint;
+    int rc = finish_index(ix, k_hint, PCRS_ALGO_GRID);
+    if (rc != PCRS_OK) {
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
+}
+
+// cut + index over one slab and its halo + selection of the slab's points: the three calls above
+// in one, with the cloud measured once (the build takes its bounds from the cut)
+int pcrs_slab_index_build_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                              size_t m, uint32_t k_hint, uint32_t parts, uint32_t part,
+                              pcrs_index **out, size_t *n_queries, int *axis_out,
+                              float slab[2]) try {
+    if (!out || !n_queries) return PCRS_ERR_INVALID_ARG;
+    *out = nullptr;
+    *n_queries = 0;
+    PCRS_TRY(bind_device(ctx));
+    if (parts == 0 || part >= parts) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "part %u of %u", part, parts);
+    if (m && (!dx || !dy || !dz)) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null column pointer");
+    std::vector<float> cuts((size_t)parts + 1);
+    SlabMeasure ms;
+    int axis = 0;
+    float halo = 0.0f;
+    size_t n_finite = 0;
+    PCRS_TRY(pcrs_slab_cuts(ctx, dx, dy, dz, m, parts, k_hint, &axis, cuts.data(), &halo, &n_finite, &ms));
+    if (axis_out) *axis_out = axis;
+    if (slab) {
+        slab[0] = cuts[part];
+        slab[1] = cuts[part + 1];
+    }
+    // points without a place in space belong to no slab, and a cloud without extent has no cuts
+    if (n_finite != m || ms.hist.empty()) return PCRS_OK;
+    pcrs_index *ix = new (std::nothrow) pcrs_index();
+    if (!ix) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    ix->ctx = ctx;
+    ix->x = dx;
+    ix->y = dy;
+    ix->z = dz;
+    ix->m = m;
+    ix->k_hint = k_hint;
+    BoxFilter qb = pcrs_no_box();
+    qb.lo[axis] = cuts[part];
+    qb.hi[axis] = cuts[part + 1];
+    if (part > 0) ix->box.lo[axis] = cuts[part] - halo;
+    if (part + 1 < parts) ix->box.hi[axis] = cuts[part + 1] + halo;
+    // the bounds of what the index takes, and no fewer points than it can take (whole bins of the
+    // cut's histogram, one more on either side for the rounding of the bin edges)
+    ix->have_bounds = true;
+    for (int a = 0; a < 3; ++a) {
+        ix->bounds_lo[a] = ms.lo[a];
+        ix->bounds_hi[a] = ms.hi[a];
+    }
+    if ((double)ix->box.lo[axis] > ix->bounds_lo[axis]) ix->bounds_lo[axis] = ix->box.lo[axis];
+    if ((double)ix->box.hi[axis] < ix->bounds_hi[axis]) ix->bounds_hi[axis] = ix->box.hi[axis];
+    {
+        const double w = ms.hist_width;
+        const long nbins = (long)ms.hist.size();
+        long b0 = (long)std::floor((ix->bounds_lo[axis] - ms.hist_lo) / w) - 1;
+        long b1 = (long)std::floor((ix->bounds_hi[axis] - ms.hist_lo) / w) + 1;
+        if (b0 < 0) b0 = 0;
+        if (b1 > nbins - 1) b1 = nbins - 1;
+        size_t upper = 0;
+        for (long b = b0; b <= b1; ++b) upper += ms.hist[(size_t)b];
+        ix->bounds_n_upper = upper;
+    }
+    int rc = ix->bounds_n_upper >= 64 ? finish_index(ix, k_hint, PCRS_ALGO_GRID) : PCRS_OK;
+    if (rc == PCRS_OK && ix->algo == PCRS_ALGO_GRID) rc = pcrs_grid_select_box(ix, qb, n_queries);
+    if (rc != PCRS_OK || ix->algo != PCRS_ALGO_GRID) {  // no grid over this slab: no index either
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return PCRS_OK;
+} catch (...) {
+    return pcrs_on_exception(ctx);
+}
+
+int pcrs_index_select_box(pcrs_index *index, const float q_lo[3], const float q_hi[3],
+                          size_t *count) try {
+    if (!index || !count) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    *count = 0;
+    if (!q_lo || !q_hi) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null box");
+    if (index->algo != PCRS_ALGO_GRID) {
+        // a box with too few points for a grid: nothing is selected by cell order here (the
+        // caller falls back to ranges of point indices)
+        index->sel_count = 0;
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "the index has no cell order");
+    }
+    BoxFilter qb;
+    for (int a = 0; a < 3; ++a) {
+        qb.lo[a] = q_lo[a];
+        qb.hi[a] = q_hi[a];
+    }
+    return pcrs_grid_select_box(index, qb, count);
+} catch (...) {
+    return pcrs_on_exception(index ? index->ctx : nullptr);
+}
+
+int pcrs_sor_normals_selected_dev(pcrs_index *index, uint32_t k_sor, uint32_t k_normals,
+                                  const float viewpoint[3], uint32_t *dpoint, float *dmean,
+                                  float *dnx, float *dny, float *dnz, size_t *n_escalated) try {
+    if (!index) return PCRS_ERR_INVALID_ARG;
+    pcrs_ctx *ctx = index->ctx;
+    PCRS_TRY(bind_device(ctx));
+    if (n_escalated) *n_escalated = 0;
+    if (index->algo != PCRS_ALGO_GRID || !index->sel_list.p)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "no queries selected (pcrs_index_select_box)");
+    const bool want_n = dnx || dny || dnz;
+    if (want_n && !(dnx && dny && dnz))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "normals need all three output columns");
+    if (dmean && k_sor == 0) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_sor must be >= 1");
+    if (want_n && (k_normals == 0 || !viewpoint))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_normals must be >= 1 with a viewpoint");
+    const size_t n = index->sel_count;
+    if (n == 0) return PCRS_OK;
+    if (!dpoint) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null point-index output");
+    DevBuf qx, qy, qz, cov;
+    PCRS_HIP_CHECK(ctx, qx.alloc(ctx, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, qy.alloc(ctx, n * sizeof(float)));
+    PCRS_HIP_CHECK(ctx, qz.alloc(ctx, n * sizeof(float)));
+    PCRS_TRY(pcrs_grid_gather_selected(index, qx.as<float>(), qy.as<float>(), qz.as<float>(), dpoint));
+    if (!dmean && !want_n) return PCRS_OK;
+    KnnQuery q;
+    q.qx = qx.as<float>();
+    q.qy = qy.as<float>();
+    q.qz = qz.as<float>();
+    q.nq = n;
+    q.coherent = true;
+    q.no_brute = true;  // what the box cannot certify is asked of an index over the whole cloud
+    KnnOut o;
+    uint32_t kneed = 1;
+    if (dmean) {
+        if (k_sor == 0xFFFFFFFFu) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "k_sor too large");
+        o.mean = dmean;
+        o.k_sor = k_sor;
+        kneed = k_sor + 1;
+    }
+    if (want_n) {
+        o.nx = dnx;
+        o.ny = dny;
+        o.nz = dnz;
+        o.k_nrm = k_normals;
+        o.vp[0] = viewpoint[0];
+        o.vp[1] = viewpoint[1];
+        o.vp[2] = viewpoint[2];
+        if (k_normals > kneed) kneed = k_normals;
+        // the covariance records are the caller's here: both indices write into them, and they
+        // are solved once, at the end
+        PCRS_HIP_CHECK(ctx, cov.alloc(ctx, PCRS_REC_FLOATS_HOST * n * sizeof(float)));
+        o.cov = cov.as<float>();
+    }
+    PCRS_TRY(run_query(index, q, o, kneed));
+    if (index->left_count) {
+        void *pin = nullptr;
+        PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &pin));
+        PCRS_TRY(pcrs_launch_publish(ctx, index->left_count, pin, sizeof(uint32_t)));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t left = *reinterpret_cast<uint32_t *>(pin);
+        if (n_escalated) *n_escalated = left;
+        if (left) {
+            if (!index->whole) {
+                pcrs_index *w = new (std::nothrow) pcrs_index();
+                if (!w) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+                w->ctx = ctx;
+                w->x = index->x;
+                w->y = index->y;
+                w->z = index->z;
+                w->m = index->m;
+                const int rc = finish_index(w, index->k_hint, PCRS_ALGO_AUTO);
+                if (rc != PCRS_OK) {
+                    delete w;
+                    return rc;
+                }
+                index->whole = w;
+            }
+            KnnQuery q2 = q;
+            q2.no_brute = false;
+            q2.only_list = index->left_list;
+            q2.only_count = index->left_count;
+            PCRS_TRY(run_query(index->whole, q2, o, kneed));
+        }
+    }
+    if (want_n)
+        PCRS_TRY(pcrs_launch_normals_from_cov(ctx, n, cov.as<float>(), q.qx, q.qy, q.qz, o));
+    return PCRS_OK;
 } catch (...) {
     return pcrs_on_exception(index ? index->ctx : nullptr);
 }

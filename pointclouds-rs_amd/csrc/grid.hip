@@ -38,20 +38,26 @@ constexpr int GB_THREADS = 256;
 
 // ----------------------------------------------------------------------------- build kernels
 
+// finite, and inside the box the index is built over (NaN fails every comparison)
+__device__ __forceinline__ bool point_taken(const BoxFilter &b, float x, float y, float z) {
+    return finite3(x, y, z) && x >= b.lo[0] && x < b.hi[0] && y >= b.lo[1] && y < b.hi[1] &&
+           z >= b.lo[2] && z < b.hi[2];
+}
+
 struct BBoxPartial {
     float lo[3], hi[3];
     unsigned long long nvalid;
 };
 
 __global__ __launch_bounds__(GB_THREADS) void bbox_kernel(const float *x, const float *y,
-                                                          const float *z, uint32_t m,
+                                                          const float *z, uint32_t m, BoxFilter box,
                                                           BBoxPartial *partials) {
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     unsigned nv = 0;
     for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < m; i += gridDim.x * GB_THREADS) {
         const float p[3] = {x[i], y[i], z[i]};
-        if (finite3(p[0], p[1], p[2])) {
+        if (point_taken(box, p[0], p[1], p[2])) {
             ++nv;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -95,6 +101,29 @@ __global__ __launch_bounds__(GB_THREADS) void bbox_kernel(const float *x, const 
     }
 }
 
+// Histogram of one coordinate of the finite points over SLAB_BINS equal bins of [lo, lo + bins/inv):
+// where to cut a cloud into slabs of equal point counts.
+constexpr int SLAB_BINS = 1024;
+__global__ __launch_bounds__(GB_THREADS) void axis_hist_kernel(const float *x, const float *y,
+                                                               const float *z, uint32_t m, int axis,
+                                                               float lo, float inv,
+                                                               uint32_t *hist) {
+    __shared__ uint32_t h[SLAB_BINS];
+    for (int t = threadIdx.x; t < SLAB_BINS; t += GB_THREADS) h[t] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < m; i += gridDim.x * GB_THREADS) {
+        const float p[3] = {x[i], y[i], z[i]};
+        if (finite3(p[0], p[1], p[2])) {
+            float f = floorf((p[axis] - lo) * inv);
+            f = fminf(fmaxf(f, 0.0f), (float)(SLAB_BINS - 1));
+            atomicAdd(&h[(int)f], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < SLAB_BINS; t += GB_THREADS)
+        if (h[t]) atomicAdd(&hist[t], h[t]);
+}
+
 __device__ __forceinline__ int cell_coord(float p, float o, float inv, int n) {
     float f = floorf((p - o) * inv);
     f = fminf(fmaxf(f, 0.0f), (float)(n - 1));
@@ -108,18 +137,48 @@ __device__ __forceinline__ uint32_t cell_index(const GridGeom &g, float x, float
     return ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
 }
 
+// Distance from the grid-relative point u to the nearest face behind which points may lie that a
+// search of the cube of half-width R around cell c has not seen: a face of the cube inside the
+// grid, or -- where the cube reaches the end of the grid -- the face of the index's box, when the
+// index left the points of the cloud beyond that face out (an open face).  +inf when there is no
+// such face: the cube then holds every point a neighbour could be.
+__device__ __forceinline__ float cube_margin(const GridGeom &g, int cx, int cy, int cz, float ux,
+                                             float uy, float uz, int R) {
+    const float u[3] = {ux, uy, uz};
+    const int c[3] = {cx, cy, cz};
+    const int n[3] = {g.nx, g.ny, g.nz};
+    float margin = __builtin_inff();
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        margin = fminf(margin, c[ax] - R > 0 ? u[ax] - (float)(c[ax] - R) * g.cell
+                                             : u[ax] - g.open_lo[ax]);
+        margin = fminf(margin, c[ax] + R < n[ax] - 1 ? (float)(c[ax] + R + 1) * g.cell - u[ax]
+                                                     : g.open_hi[ax] - u[ax]);
+    }
+    return margin;
+}
+// Distance from u to the nearest open face of the index's box (+inf: the index holds the whole
+// cloud): a ball that reaches farther cannot be searched in this index alone.
+__device__ __forceinline__ float open_face_distance(const GridGeom &g, float ux, float uy, float uz) {
+    const float u[3] = {ux, uy, uz};
+    float d = __builtin_inff();
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) d = fminf(d, fminf(u[ax] - g.open_lo[ax], g.open_hi[ax] - u[ax]));
+    return d;
+}
+
 // cell id per point (PCRS_NO_INDEX for non-finite points), the cell histogram and the number of
 // non-empty cells (the point that finds a cell empty counts it)
 __global__ __launch_bounds__(GB_THREADS) void cell_count_kernel(const float *x, const float *y,
                                                                 const float *z, uint32_t m,
-                                                                GridGeom g, uint32_t *cell_id,
-                                                                uint32_t *counts,
+                                                                GridGeom g, BoxFilter box,
+                                                                uint32_t *cell_id, uint32_t *counts,
                                                                 uint32_t *nonempty) {
     unsigned opened = 0;
     for (uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x; i < m; i += gridDim.x * GB_THREADS) {
         const float px = x[i], py = y[i], pz = z[i];
         uint32_t c = PCRS_NO_INDEX;
-        if (finite3(px, py, pz)) {
+        if (point_taken(box, px, py, pz)) {
             c = cell_index(g, px, py, pz);
             opened += (atomicAdd(&counts[c], 1u) == 0u) ? 1u : 0u;
         }
@@ -257,6 +316,7 @@ __global__ __launch_bounds__(GB_THREADS) void scatter_kernel(const float *x, con
 // global-memory version above needs one device-scope atomic per point and pass.
 struct SortPlan {
     GridGeom g;
+    BoxFilter box;     // points outside it are left out, like the non-finite ones
     uint32_t shift;    // log2(cells per coarse bucket), <= FINE_MAX_SHIFT
     uint32_t nb;       // coarse buckets
     uint32_t nblk;     // level-1 blocks
@@ -297,7 +357,7 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_hist_kernel(const float *x,
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (finite3(px[j], py[j], pz[j]))
+            if (point_taken(sp.box, px[j], py[j], pz[j]))
                 atomicAdd(&hist[cell_index(sp.g, px[j], py[j], pz[j]) >> sp.shift], 1u);
     }
     __syncthreads();
@@ -330,7 +390,7 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_scatter_kernel(const float 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (finite3(px[j], py[j], pz[j])) {
+            if (point_taken(sp.box, px[j], py[j], pz[j])) {
                 const uint32_t at =
                     atomicAdd(&cursor[cell_index(sp.g, px[j], py[j], pz[j]) >> sp.shift], 1u);
                 tmp[at] = make_float4(px[j], py[j], pz[j], __uint_as_float(i0 + j * GB_THREADS));
@@ -695,37 +755,80 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             for (int s = K - 1; s > 0; --s) D[s] = __builtin_amdgcn_fmed3f(d2, D[s - 1], D[s]);
             D[0] = fminf(D[0], d2);
         };
-        walk_cube3(
-            a, cx, cy, cz, q3,
-            [&](const float(&d2)[4], uint32_t) {
+        // A cube of thousands of points is no work for a single lane (a blob of a hundred
+        // thousand points in a few cells would keep every lane of its waves walking all of it):
+        // the nine row ranges tell before anything is walked.  Such a query first looks at the
+        // start of its own cell: where the cloud repeats one point over and over (returns a sensor
+        // parks at the origin, padding) the list is full of zero distances after a handful of
+        // candidates, and a list of zeros cannot get any better -- the query is answered here and
+        // now.  Otherwise it goes, flagged, to the wave-per-query kernel, which samples crowded
+        // regions instead of walking them.
+        uint32_t probe0 = 0, probe1 = 0;  // the slots the probe looked at (probe1 > probe0: answered by it)
+        {
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            uint32_t cube_pts = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) insert(d2[j]);
-            },
-            [&](const pcrs_p3 &p, uint32_t, bool live) {
-                const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
-                insert(live ? d2 : __builtin_inff());  // +inf passes through without a trace
-            });
+            for (int i = 0; i < 9; ++i) {
+                const int yy = cy + i % 3 - 1, zz = cz + i / 3 - 1;
+                if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                    const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                    cube_pts += a.cell_start[row + x1 + 1] - a.cell_start[row + x0];
+                }
+            }
+            if (cube_pts > a.heavy) {
+                const uint32_t own = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+                const uint32_t c0 = a.cell_start[own], c1 = a.cell_start[own + 1];
+                const uint32_t pe = c1 - c0 > 64u ? c0 + 64u : c1;
+                const pcrs_p3 *base = reinterpret_cast<const pcrs_p3 *>(a.spts3);
+                for (uint32_t sl = c0; sl < pe; ++sl) {
+                    const pcrs_p3 p = base[sl];
+                    insert(sqdist(qx, qy, qz, p.x, p.y, p.z));
+                }
+                float t0 = __builtin_inff();
+#pragma unroll
+                for (int i = 0; i < K; ++i)
+                    if ((uint32_t)i == a.kcert - 1) t0 = D[i];
+                // (neighbour lists name their neighbours: which of the repeated points those are
+                // is the wave kernel's to find out)
+                const bool lists = COLLECT && (out.idx || out.dist || out.count);
+                if (t0 == 0.0f && !lists) {
+                    probe0 = c0;
+                    probe1 = pe;
+                } else {
+                    if (a.fail_list) {
+                        const uint32_t f = atomicAdd(a.fail_count, 1u);
+                        a.fail_list[f] = qi | PCRS_HEAVY_FLAG;
+                        if (a.fail_bound) a.fail_bound[f] = __builtin_inff();
+                    }
+                    continue;
+                }
+            }
+        }
+        const bool probed = probe1 > probe0;
+        if (!probed)
+            walk_cube3(
+                a, cx, cy, cz, q3,
+                [&](const float(&d2)[4], uint32_t) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) insert(d2[j]);
+                },
+                [&](const pcrs_p3 &p, uint32_t, bool live) {
+                    const float d2 = sqdist_pk(qxy, qz, make_float4(p.x, p.y, p.z, 0.0f));
+                    insert(live ? d2 : __builtin_inff());  // +inf passes through without a trace
+                });
 
         // ---- certification: every point outside the cube is farther than `margin`
         const int R = a.R;
-        const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
-                           (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
+        // (a list of zero distances is final: a point at distance zero lies where the query lies,
+        // in the query's own cell)
+        const float margin = cube_margin(g, cx, cy, cz, ux, uy, uz, R);
+        const bool whole = probed || !(margin < __builtin_inff());
         bool certified = whole;
         float tau_cert = __builtin_inff();
 #pragma unroll
         for (int i = 0; i < K; ++i)
             if ((uint32_t)i == a.kcert - 1) tau_cert = D[i];
         if (!whole) {
-            float margin = __builtin_inff();
-            const float u[3] = {ux, uy, uz};
-            const int c[3] = {cx, cy, cz};
-            const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                if (c[ax] + R < n[ax] - 1)
-                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-            }
             // slack covers the f32 rounding of the cell assignment and of the offsets above
             const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
             const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
@@ -774,6 +877,15 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
                     ++hits;
                 }
             };
+            if (probed) {
+                // the neighbours all lie where the query lies, so the covariance is the same
+                // whichever of them are taken: the first kcollect the probe met
+                const pcrs_p3 *base = reinterpret_cast<const pcrs_p3 *>(a.spts3);
+                for (uint32_t sl = probe0; sl < probe1 && hits < a.kcollect; ++sl) {
+                    const pcrs_p3 p = base[sl];
+                    take(sqdist(qx, qy, qz, p.x, p.y, p.z), sl);
+                }
+            } else
             walk_cube3(
                 a, cx, cy, cz, q3,
                 [&](const float(&d2)[4], uint32_t slot) {
@@ -1031,8 +1143,8 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
 
         // ---- certification: every point outside the cube is farther than `margin`
         const int R = a.R;
-        const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
-                           (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
+        const float margin = cube_margin(g, cx, cy, cz, ux, uy, uz, R);
+        const bool whole = !(margin < __builtin_inff());
         bool certified = whole;
         // the keff-th distance, rounded up to the key's resolution (+inf when there is none)
         uint32_t tb = TAG_INF;
@@ -1041,16 +1153,6 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
             if ((uint32_t)i == keff - 1 && D[i] < TAG_INF) tb = D[i] | TAG_MASK;
         const float tau_cert = __uint_as_float(tb);
         if (!whole) {
-            float margin = __builtin_inff();
-            const float u[3] = {ux, uy, uz};
-            const int c[3] = {cx, cy, cz};
-            const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                if (c[ax] + R < n[ax] - 1)
-                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-            }
             const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
             const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
             certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
@@ -1296,6 +1398,10 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         bool certified = false;
         const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
         const float allow = g.slack + 2e-6f * amax;  // f32 rounding of cell assignment and offsets
+        // An index over a box of the cloud: the ball of a result must end before the box's open
+        // faces, or points the index does not hold could belong to the answer.
+        const float open_dist = open_face_distance(g, ux, uy, uz);
+        auto fits = [&](float d2) { return sqrtf(d2) * (1.0f + 4e-6f) + 3.0f * allow < open_dist; };
         // K smallest distances of a box of cells (all of it, every stride-th point of it, or the
         // part of it inside a ball), merged so that every lane holds them
         auto search_box = [&](const BallClip &clip, uint32_t stride) {
@@ -1396,6 +1502,7 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
             const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
                                (z0 == 0) && (z1 == g.nz - 1);
+            const bool closed_whole = whole && !(open_dist < __builtin_inff());
             if (!counted)
                 n_region = (whole && clip.r < 0.0f) ? a.nvalid
                                                     : wave_box_count(a, x0, x1, y0, y1, z0, z1, lane, clip);
@@ -1419,20 +1526,12 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
                 // every point of the region was seen: a ball around a bound holds the answer (the
                 // comparison can only fail if the ball missed a cell it should have had: such a
                 // query is left to the brute-force stage rather than answered wrongly)
-                certified = whole || (clip.r >= 0.0f && (K == 1 || tau_cert <= bound));
+                certified = closed_whole ||
+                            (clip.r >= 0.0f && (K == 1 || tau_cert <= bound) &&
+                             fits(K == 1 ? fminf(tau_cert, bound) : tau_cert));
                 if (!certified && clip.r >= 0.0f) break;
                 if (!certified) {
-                    float margin = __builtin_inff();
-                    const float u[3] = {ux, uy, uz};
-                    const int c[3] = {cx, cy, cz};
-                    const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        if (c[ax] - R > 0)
-                            margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                        if (c[ax] + R < n[ax] - 1)
-                            margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-                    }
+                    const float margin = cube_margin(g, cx, cy, cz, ux, uy, uz, R);
                     const float m = (margin - allow) * (1.0f - 2e-6f);
                     certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f) ||
                                                (K == 1 && a.useful_d2 < (m * m) * (1.0f - 2e-6f)));
@@ -1466,7 +1565,8 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             if (stride > 1u && n_ball > n_region / 2u) {
                 x0 = bx0, x1 = bx1, y0 = by0, y1 = by1, z0 = bz0, z1 = bz1;
                 search_box(clip, 1u);
-                certified = true;
+                const float t = kth(a.kcert);
+                certified = fits(K == 1 ? fminf(t, bound) : t);
                 break;
             }
             n_region = n_ball;
@@ -1578,24 +1678,37 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
 constexpr int OWN_PER_THREAD = 4;
 constexpr int OWN_BLOCK = GB_THREADS * OWN_PER_THREAD;
 
+// Which sorted slots are queries: original index in [q_begin, q_begin + q_len) and, with boxes,
+// inside `in` but not inside `ex` (a slab of a sharded cloud; a level of a refined index without
+// the part the next level answers).
+struct SlotChoice {
+    uint32_t q_begin, q_len;
+    bool boxes;
+    BoxFilter in, ex;
+};
 __device__ __forceinline__ uint32_t owned_flags(const float4 *spts, uint32_t nvalid, uint32_t first,
-                                                uint32_t q_begin, uint32_t q_len) {
+                                                const SlotChoice &ch) {
     uint32_t f = 0;
 #pragma unroll
     for (int i = 0; i < OWN_PER_THREAD; ++i) {
         const uint32_t s = first + i;
-        if (s < nvalid && (__float_as_uint(spts[s].w) - q_begin) < q_len) f |= 1u << i;
+        if (s < nvalid) {
+            const float4 p = spts[s];
+            bool own = (__float_as_uint(p.w) - ch.q_begin) < ch.q_len;
+            if (ch.boxes)
+                own = own && point_taken(ch.in, p.x, p.y, p.z) && !point_taken(ch.ex, p.x, p.y, p.z);
+            if (own) f |= 1u << i;
+        }
     }
     return f;
 }
 
 __global__ __launch_bounds__(GB_THREADS) void owned_count_kernel(const float4 *spts,
-                                                                 uint32_t nvalid, uint32_t q_begin,
-                                                                 uint32_t q_len,
+                                                                 uint32_t nvalid, SlotChoice ch,
                                                                  uint32_t *block_count) {
     __shared__ uint32_t wsum[GB_THREADS / 64];
     const uint32_t first = blockIdx.x * OWN_BLOCK + threadIdx.x * OWN_PER_THREAD;
-    uint32_t c = __popc(owned_flags(spts, nvalid, first, q_begin, q_len));
+    uint32_t c = __popc(owned_flags(spts, nvalid, first, ch));
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -1603,13 +1716,12 @@ __global__ __launch_bounds__(GB_THREADS) void owned_count_kernel(const float4 *s
 }
 
 __global__ __launch_bounds__(GB_THREADS) void owned_write_kernel(const float4 *spts,
-                                                                 uint32_t nvalid, uint32_t q_begin,
-                                                                 uint32_t q_len,
+                                                                 uint32_t nvalid, SlotChoice ch,
                                                                  const uint32_t *block_offset,
                                                                  uint32_t *list) {
     __shared__ uint32_t wsum[GB_THREADS / 64];
     const uint32_t first = blockIdx.x * OWN_BLOCK + threadIdx.x * OWN_PER_THREAD;
-    const uint32_t f = owned_flags(spts, nvalid, first, q_begin, q_len);
+    const uint32_t f = owned_flags(spts, nvalid, first, ch);
     const uint32_t c = __popc(f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = c;
@@ -1641,6 +1753,8 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
     const int cz = cell_coord(qz, g.oz, g.inv, g.nz);
     const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
     const float allow = g.slack + 2e-6f * amax;
+    const float open_dist = open_face_distance(g, ux, uy, uz);  // see knn_wave_kernel
+    auto fits = [&](float d2) { return sqrtf(d2) * (1.0f + 4e-6f) + 3.0f * allow < open_dist; };
     uint64_t best = PCRS_EMPTY_KEY;
     float best_d2 = __builtin_inff();
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
@@ -1684,22 +1798,14 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
         z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
         const bool whole = (x0 == 0) && (x1 == g.nx - 1) && (y0 == 0) && (y1 == g.ny - 1) &&
                            (z0 == 0) && (z1 == g.nz - 1);
+        const bool closed_whole = whole && !(open_dist < __builtin_inff());
         if (!counted)
             n_region = (whole && clip.r < 0.0f) ? a.nvalid
                                                 : wave_box_count(a, x0, x1, y0, y1, z0, z1, lane, clip);
         counted = false;
         if (clip.r < 0.0f && !whole && n_region == 0u) {  // an empty cube
             // ... which still settles the query when nothing outside it can be of use
-            float margin = __builtin_inff();
-            const float u[3] = {ux, uy, uz};
-            const int c[3] = {cx, cy, cz};
-            const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                if (c[ax] + R < n[ax] - 1)
-                    margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-            }
+            const float margin = cube_margin(g, cx, cy, cz, ux, uy, uz, R);
             const float m = (margin - allow) * (1.0f - 2e-6f);
             if (m > 0.0f && a.useful_d2 < (m * m) * (1.0f - 2e-6f)) {
                 best = PCRS_EMPTY_KEY;
@@ -1720,18 +1826,13 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
             search_box(clip, 1u);
         }
         if (stride == 1u) {
-            certified = whole || clip.r >= 0.0f;
+            // (a ball that was searched in full settles the query when it ends before the open
+            // faces of the index's box; one that does not leaves it to the next stage)
+            certified = closed_whole ||
+                        (clip.r >= 0.0f && fits(fminf(fminf(best_d2, a.useful_d2), bound)));
+            if (!certified && clip.r >= 0.0f) break;
             if (!certified) {
-                float margin = __builtin_inff();
-                const float u[3] = {ux, uy, uz};
-                const int c[3] = {cx, cy, cz};
-                const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    if (c[ax] - R > 0) margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                    if (c[ax] + R < n[ax] - 1)
-                        margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-                }
+                const float margin = cube_margin(g, cx, cy, cz, ux, uy, uz, R);
                 const float m = (margin - allow) * (1.0f - 2e-6f);
                 certified = (m > 0.0f) && (best_d2 < (m * m) * (1.0f - 2e-6f) ||
                                            a.useful_d2 < (m * m) * (1.0f - 2e-6f));
@@ -1761,7 +1862,7 @@ __device__ __forceinline__ void nn1_wave_retry(const CellArgs &a, const KnnOut &
         if (stride > 1u && n_ball > n_region / 2u) {  // a sample that did not narrow the region
             x0 = bx0, x1 = bx1, y0 = by0, y1 = by1, z0 = bz0, z1 = bz1;
             search_box(clip, 1u);
-            certified = true;
+            certified = fits(fminf(fminf(best_d2, a.useful_d2), bound));
             break;
         }
         n_region = n_ball;
@@ -1938,21 +2039,10 @@ void nn_cell_kernel(CellArgs a, KnnOut out) {
                 retry = qi | PCRS_HEAVY_FLAG;
             } else {
                 const int R = 1;
-                const bool whole = (cx - R <= 0) && (cx + R >= g.nx - 1) && (cy - R <= 0) &&
-                                   (cy + R >= g.ny - 1) && (cz - R <= 0) && (cz + R >= g.nz - 1);
+                const float margin = cube_margin(g, cx, cy, cz, ux, uy, uz, R);
+                const bool whole = !(margin < __builtin_inff());
                 bool certified = whole;
                 if (!whole) {
-                    float margin = __builtin_inff();
-                    const float u[3] = {ux, uy, uz};
-                    const int c[3] = {cx, cy, cz};
-                    const int n[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        if (c[ax] - R > 0)
-                            margin = fminf(margin, u[ax] - (float)(c[ax] - R) * g.cell);
-                        if (c[ax] + R < n[ax] - 1)
-                            margin = fminf(margin, (float)(c[ax] + R + 1) * g.cell - u[ax]);
-                    }
                     const float amax = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
                     const float m = (margin - (g.slack + 2e-6f * amax)) * (1.0f - 2e-6f);
                     // either the nearest point is certainly inside the cube, or everything outside
@@ -2073,6 +2163,20 @@ __global__ __launch_bounds__(GB_THREADS) void unpack_sorted_kernel(const float4 
     perm[i] = __float_as_uint(p.w);
 }
 
+// The same for a list of slots: columns and original indices of the listed points, in list order.
+__global__ __launch_bounds__(GB_THREADS) void gather_slots_kernel(const float4 *spts,
+                                                                  const uint32_t *list, uint32_t n,
+                                                                  float *ox, float *oy, float *oz,
+                                                                  uint32_t *perm) {
+    const uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = spts[list[i]];
+    ox[i] = p.x;
+    oy[i] = p.y;
+    oz[i] = p.z;
+    perm[i] = __float_as_uint(p.w);
+}
+
 // x, y, z of the sorted points as 12-byte records, once per build
 __global__ __launch_bounds__(GB_THREADS) void pack_xyz_kernel(const float4 *spts, uint32_t n,
                                                               float *spts3) {
@@ -2171,13 +2275,20 @@ void make_geometry(const double lo[3], const double ext[3], double emax, double 
     g->ny = dims[1];
     g->nz = dims[2];
     g->slack = (float)(2e-6 * (emax + cell));
+    for (int a = 0; a < 3; ++a) {  // faces with nothing behind them (the caller opens the others)
+        g->open_lo[a] = -__builtin_inff();
+        g->open_hi[a] = __builtin_inff();
+    }
     *ncell = (uint32_t)dims[0] * (uint32_t)dims[1] * (uint32_t)dims[2];
     *cell_used = cell;
 }
 
 // Shape of the two-level sort for this grid; false when the grid has more cells than 8192 coarse
 // buckets of 4096 (the global-atomic counting sort handles those).
-bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
+// m: points in the columns; n_taken: how many of them the sort will place (fewer when the index
+// covers a box of the cloud): the buckets are sized for those, the blocks of level 1 share out m.
+bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp, uint32_t n_taken = 0) {
+    if (n_taken == 0 || n_taken > m) n_taken = m;
     // experiments only: PCRS_GRID_SORT=atomic keeps the one-level sort
     if (const char *e = getenv("PCRS_GRID_SORT"))
         if (e[0] == 'a') return false;
@@ -2185,12 +2296,13 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp) {
     // LDS (one read, one linear write).  Few large buckets leave most of the chip idle and turn
     // level 2 into long serial loops; the table of per-block counts bounds their number.
     uint32_t nb_max = 1024u;
-    if (m / 1536u > nb_max) nb_max = m / 1536u < 8192u ? m / 1536u : 8192u;
+    if (n_taken / 1536u > nb_max) nb_max = n_taken / 1536u < 8192u ? n_taken / 1536u : 8192u;
     if (ncell > (nb_max << FINE_MAX_SHIFT)) nb_max = 8192u;
     uint32_t shift = 0;
     while (((ncell + (1u << shift) - 1) >> shift) > nb_max) ++shift;
     if (shift > FINE_MAX_SHIFT) return false;
     sp->g = g;
+    sp->box = pcrs_no_box();
     sp->shift = shift;
     sp->nb = (ncell + (1u << shift) - 1) >> shift;
     sp->ncell = ncell;
@@ -2254,17 +2366,30 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     void *pin = nullptr;
     PCRS_TRY(pcrs_ctx_pinned(ctx, nb * sizeof(BBoxPartial) + 64, &pin));
     BBoxPartial *hp = reinterpret_cast<BBoxPartial *>(pin);
-    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
-                       ix->z, m, hp);
-    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const BoxFilter box = ix->box;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     size_t nvalid = 0;
-    for (unsigned b = 0; b < nb; ++b) {
-        const BBoxPartial &p = hp[b];
-        nvalid += p.nvalid;
+    // A caller that has just measured the cloud (the slab cut of a sharded run) brings bounds that
+    // hold every point the index takes, and an upper limit of their number: no pass over the
+    // columns for them, the exact count comes back with the first sort's statistics.
+    bool count_exact = !ix->have_bounds;
+    if (ix->have_bounds) {
         for (int a = 0; a < 3; ++a) {
-            if (p.lo[a] < lo[a]) lo[a] = p.lo[a];
-            if (p.hi[a] > hi[a]) hi[a] = p.hi[a];
+            lo[a] = ix->bounds_lo[a];
+            hi[a] = ix->bounds_hi[a];
+        }
+        nvalid = ix->bounds_n_upper;
+    } else {
+        hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
+                           ix->z, m, box, hp);
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (unsigned b = 0; b < nb; ++b) {
+            const BBoxPartial &p = hp[b];
+            nvalid += p.nvalid;
+            for (int a = 0; a < 3; ++a) {
+                if (p.lo[a] < lo[a]) lo[a] = p.lo[a];
+                if (p.hi[a] > hi[a]) hi[a] = p.hi[a];
+            }
         }
     }
     ix->nvalid = nvalid;
@@ -2274,7 +2399,12 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         ext[a] = hi[a] - lo[a];
         if (ext[a] > emax) emax = ext[a];
     }
-    if (!(emax > 0.0) || !(emax < 1e30)) return PCRS_OK;  // coincident points or overflow
+    if (!(emax < 1e30)) return PCRS_OK;  // coordinates whose differences overflow: brute force
+    // All finite points in one place: a grid of a single cell.  Every query then sees the whole
+    // cloud as its cube, and the searches' shortcut for a list full of zero distances answers the
+    // cloud's own points after a handful of candidates (the tiled brute-force kernel would compare
+    // every point with every other).
+    const bool coincident = !(emax > 0.0);
 
     // 2. cell size: start from the bounding-box density, then shrink while the occupied cells
     //    are much fuller than the target (surfaces and clusters leave most of the box empty).
@@ -2288,8 +2418,8 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     for (int a = 0; a < 3; ++a) eff[a] = ext[a] > 1e-3 * emax ? ext[a] : 1e-3 * emax;
     double cell = cbrt(eff[0] * eff[1] * eff[2] * P / (double)nvalid);
     // a radius search wants cells of the radius (one attempt, no occupancy feedback)
-    const bool fixed_cell = cell_request > 0.0f && cell_request < 1e30f;
-    if (fixed_cell) cell = (double)cell_request;
+    const bool fixed_cell = coincident || (cell_request > 0.0f && cell_request < 1e30f);
+    if (fixed_cell) cell = coincident ? 1.0 : (double)cell_request;
     // a cloud like the one before it (same list length, size and extent within 30 %) starts from
     // the cell that one ended with, scaled by the change in density a surface would show
     static const bool use_hint = [] {  // experiments only: PCRS_GRID_HINT=0
@@ -2337,9 +2467,16 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         double used = cell;
         make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
         cell = used;
+        // a bounded side of the box is an open face: the cloud may go on behind it
+        for (int a = 0; a < 3; ++a) {
+            const float o = a == 0 ? g.ox : (a == 1 ? g.oy : g.oz);
+            if (box.lo[a] > -__builtin_inff()) g.open_lo[a] = (float)((double)box.lo[a] - (double)o);
+            if (box.hi[a] < __builtin_inff()) g.open_hi[a] = (float)((double)box.hi[a] - (double)o);
+        }
         uint32_t *d_nonempty = counts.as<uint32_t>() + nonempty_slot(ncell);
         SortPlan sp{};
-        const bool two_level = plan_sort(g, ncell, m, &sp);
+        const bool two_level = plan_sort(g, ncell, m, &sp, (uint32_t)nvalid);
+        sp.box = box;
         if (two_level) {
             // the whole sort is cheaper than one pass of global atomics, so every attempt sorts
             const size_t entries = (size_t)sp.nb * sp.nblk;  // differs between attempts
@@ -2364,13 +2501,26 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 6) * sizeof(uint32_t),
                                                ctx->stream));
             hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
-                               ix->y, ix->z, m, g, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
+                               ix->y, ix->z, m, g, box, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
                                d_nonempty);
         }
         sorted_done = two_level;
-        if (attempt == 3 || fixed_cell) break;
+        if (!count_exact) {  // the number of points the sort placed, behind its table
+            if (!two_level)
+                return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "grid too large for a build from bounds");
+            PCRS_TRY(pcrs_launch_publish(ctx, table.as<uint32_t>() + (size_t)sp.nb * sp.nblk,
+                                         h_nonempty + 8, sizeof(uint32_t)));
+        }
+        if ((attempt == 3 || fixed_cell) && count_exact) break;
         PCRS_TRY(pcrs_launch_publish(ctx, d_nonempty, h_nonempty, 4 * sizeof(uint32_t)));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!count_exact) {
+            nvalid = h_nonempty[8];
+            ix->nvalid = nvalid;
+            count_exact = true;
+            if (nvalid < 64) return PCRS_OK;  // brute force (the sort's buffers go back to the pool)
+        }
+        if (attempt == 3 || fixed_cell) break;
         const uint32_t nonempty = *h_nonempty;
         double occ = (double)nvalid / (double)(nonempty ? nonempty : 1);
         if (two_level && weighted_occupancy) {
@@ -2490,6 +2640,90 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         ctx->grid_hint.k_hint = k_hint;
     }
     ix->algo = PCRS_ALGO_GRID;
+    return PCRS_OK;
+}
+
+// Cuts a cloud into `parts` slabs of (nearly) equal point counts along its longest axis: slab r
+// holds the finite points with cuts[r] <= p[axis] < cuts[r + 1] (cuts[0] = -inf, cuts[parts] =
+// +inf).  A pure function of the columns, so every process that holds the same cloud derives the
+// same cuts.  halo: how far beyond its slab an index should reach so that the neighbourhoods of
+// nearly all of the slab's points lie inside it (a few times the distance within which a point of
+// a cloud of this density finds k neighbours).
+int pcrs_slab_cuts(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t m,
+                   uint32_t parts, uint32_t k_hint, int *axis_out, float *cuts, float *halo,
+                   size_t *n_finite, SlabMeasure *measure) {
+    for (uint32_t r = 0; r <= parts; ++r) cuts[r] = r == 0 ? -INFINITY : INFINITY;
+    *axis_out = 0;
+    *halo = 0.0f;
+    *n_finite = 0;
+    if (m == 0 || parts == 0) return PCRS_OK;
+    if (m >= 0xFFFFFFFFull)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    const unsigned nb = grid_for(ctx, m, GB_THREADS);
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, std::max<size_t>(nb * sizeof(BBoxPartial), SLAB_BINS * sizeof(uint32_t)) + 64, &pin));
+    BBoxPartial *hp = reinterpret_cast<BBoxPartial *>(pin);
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, x, y, z, (uint32_t)m,
+                       pcrs_no_box(), hp);
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    size_t nvalid = 0;
+    for (unsigned b = 0; b < nb; ++b) {
+        nvalid += hp[b].nvalid;
+        for (int a = 0; a < 3; ++a) {
+            if (hp[b].lo[a] < lo[a]) lo[a] = hp[b].lo[a];
+            if (hp[b].hi[a] > hi[a]) hi[a] = hp[b].hi[a];
+        }
+    }
+    *n_finite = nvalid;
+    if (nvalid == 0) return PCRS_OK;
+    int axis = 0;
+    double ext[3], emax = 0.0, vol = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = hi[a] - lo[a];
+        if (ext[a] > emax) {
+            emax = ext[a];
+            axis = a;
+        }
+    }
+    *axis_out = axis;
+    if (!(emax > 0.0) || !(emax < 1e30)) return PCRS_OK;  // one slab holds everything
+    for (int a = 0; a < 3; ++a) vol *= ext[a] > 1e-3 * emax ? ext[a] : 1e-3 * emax;
+    const double kk = (double)(k_hint ? k_hint : 16);
+    *halo = (float)(2.0 * cbrt(vol * kk / (double)nvalid));
+    DevBuf hist;
+    PCRS_HIP_CHECK(ctx, hist.alloc(ctx, SLAB_BINS * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(hist.p, 0, SLAB_BINS * sizeof(uint32_t), ctx->stream));
+    const float flo = (float)lo[axis];
+    const float width = (float)(emax / SLAB_BINS * (1.0 + 1e-6));
+    const float inv = 1.0f / width;
+    hipLaunchKernelGGL(axis_hist_kernel, dim3(std::min(nb, 512u)), dim3(GB_THREADS), 0, ctx->stream, x,
+                       y, z, (uint32_t)m, axis, flo, inv, hist.as<uint32_t>());
+    PCRS_TRY(pcrs_launch_publish(ctx, hist.p, pin, SLAB_BINS * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(pin);
+    if (measure) {
+        for (int a = 0; a < 3; ++a) {
+            measure->lo[a] = lo[a];
+            measure->hi[a] = hi[a];
+        }
+        measure->hist_lo = flo;
+        measure->hist_width = width;
+        measure->hist.assign(h, h + SLAB_BINS);
+    }
+    // cut r at the lower edge of the first bin whose running count reaches r * n / parts
+    size_t run = 0;
+    uint32_t r = 1;
+    for (int b = 0; b < SLAB_BINS && r < parts; ++b) {
+        while (r < parts && run >= (size_t)(((unsigned long long)r * nvalid) / parts)) {
+            cuts[r] = flo + (float)b * width;
+            ++r;
+        }
+        run += h[b];
+    }
+    for (; r < parts; ++r) cuts[r] = INFINITY;  // (empty slabs at the end of a degenerate cloud)
+    for (uint32_t q = 1; q < parts; ++q)  // monotone, whatever the rounding of the edges did
+        if (cuts[q] < cuts[q - 1]) cuts[q] = cuts[q - 1];
     return PCRS_OK;
 }
 
@@ -2622,6 +2856,17 @@ int pcrs_launch_radius_fill_grid(pcrs_index *ix, const KnnQuery &q, float radius
     return PCRS_OK;
 }
 
+int pcrs_launch_normals_from_cov(pcrs_ctx *ctx, size_t nq, const float *cov, const float *qx,
+                                 const float *qy, const float *qz, const KnnOut &out) {
+    if (nq == 0) return PCRS_OK;
+    hipLaunchKernelGGL(normals_from_cov_kernel, dim3((unsigned)((nq + GB_THREADS - 1) / GB_THREADS)),
+                       dim3(GB_THREADS), 0, ctx->stream, (uint32_t)nq, cov, qx, qy, qz, out);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+pcrs_index::~pcrs_index() { delete whole; }
+
 int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums,
                          uint32_t *total_out) {
     if (n == 0) {
@@ -2647,6 +2892,63 @@ int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums
 }
 
 // ----------------------------------------------------------------------------- host: query
+
+// The sorted slots that `ch` picks, in slot order, into list (room for nvalid entries); their
+// number into *d_count (device).  Count per block of 1024 slots, scan, ordered write.
+static int choose_slots(pcrs_index *ix, const SlotChoice &ch, uint32_t *list, uint32_t *d_count) {
+    pcrs_ctx *ctx = ix->ctx;
+    DevBuf own_counts, own_sums;
+    const uint32_t oblocks = (uint32_t)((ix->nvalid + OWN_BLOCK - 1) / OWN_BLOCK);
+    PCRS_HIP_CHECK(ctx, own_counts.alloc(ctx, ((size_t)oblocks + 8) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, own_sums.alloc(ctx, ((size_t)oblocks / 1024 + 4) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(owned_count_kernel, dim3(oblocks), dim3(GB_THREADS), 0, ctx->stream,
+                       ix->spts.as<float4>(), (uint32_t)ix->nvalid, ch, own_counts.as<uint32_t>());
+    PCRS_TRY(pcrs_launch_scan_u32(ctx, own_counts.as<uint32_t>(), oblocks, own_sums.as<uint32_t>(),
+                                  d_count));
+    hipLaunchKernelGGL(owned_write_kernel, dim3(oblocks), dim3(GB_THREADS), 0, ctx->stream,
+                       ix->spts.as<float4>(), (uint32_t)ix->nvalid, ch, own_counts.as<uint32_t>(),
+                       list);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// The indexed points inside a box as a query set (the queries a rank owns of an index over its
+// slab plus a halo): their slots are kept in the index, their number comes back to the host.
+int pcrs_grid_select_box(pcrs_index *ix, const BoxFilter &qbox, size_t *count) {
+    pcrs_ctx *ctx = ix->ctx;
+    *count = 0;
+    if (ix->algo != PCRS_ALGO_GRID || ix->nvalid == 0)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "index has no grid");
+    PCRS_HIP_CHECK(ctx, ix->sel_list.alloc(ctx, (ix->nvalid + 2) * sizeof(uint32_t)));
+    SlotChoice ch{};
+    ch.q_begin = 0;
+    ch.q_len = 0xFFFFFFFFu;
+    ch.boxes = true;
+    ch.in = qbox;
+    for (int a = 0; a < 3; ++a) ch.ex.lo[a] = ch.ex.hi[a] = 0.0f;  // an empty box: excludes nothing
+    uint32_t *d_count = ix->sel_list.as<uint32_t>() + ix->nvalid;
+    PCRS_TRY(choose_slots(ix, ch, ix->sel_list.as<uint32_t>(), d_count));
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &pin));
+    PCRS_TRY(pcrs_launch_publish(ctx, d_count, pin, sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ix->sel_count = *reinterpret_cast<uint32_t *>(pin);
+    *count = ix->sel_count;
+    return PCRS_OK;
+}
+
+// Columns and original indices of the selected points, in cell order.
+int pcrs_grid_gather_selected(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (!ix->sel_list.p) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "no queries selected");
+    const uint32_t n = ix->sel_count;
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(gather_slots_kernel, dim3((n + GB_THREADS - 1) / GB_THREADS), dim3(GB_THREADS),
+                       0, ctx->stream, ix->spts.as<float4>(), ix->sel_list.as<uint32_t>(), n, ox, oy,
+                       oz, perm);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
 
 int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in, uint32_t kneed) {
     pcrs_ctx *ctx = ix->ctx;
@@ -2785,12 +3087,14 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
 
     // stage 1: the 27-cell cube over every query
     a.R = 1;
-    a.heavy = nq < PCRS_HEAVY_FLAG ? 2048u : 0xFFFFFFFFu;  // the flag needs bit 31 of the entry
+    // cubes beyond this many points leave the lane-per-query kernels for the wave-per-query one
+    // (2048 for eight lanes per query, 8192 for one); the flag needs bit 31 of the list entry
+    a.heavy = nq >= PCRS_HEAVY_FLAG ? 0xFFFFFFFFu : (nn_only ? 2048u : 8192u);
     a.fail_list = listA;
     a.fail_count = &counters[0];
     a.fail_bound = nn_only ? nullptr : boundA;
     unsigned blocks1 = (unsigned)((nq + GB_THREADS - 1) / GB_THREADS);
-    DevBuf own_counts, own_sums, q_table, q_sums, q_tmp, q_sorted, q_cells;
+    DevBuf q_table, q_sums, q_tmp, q_sorted, q_cells;
     bool sorted_queries = false;
     if (q.self && !nn_only) {
         a.q_begin = (uint32_t)q.out_offset;
@@ -2801,21 +3105,21 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
             blocks1 = (unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS);
         } else {
             // a sub-range: compact its sorted slots first so that every wave is full
-            const uint32_t oblocks = (uint32_t)((ix->nvalid + OWN_BLOCK - 1) / OWN_BLOCK);
-            PCRS_HIP_CHECK(ctx, own_counts.alloc(ctx, ((size_t)oblocks + 8) * sizeof(uint32_t)));
-            PCRS_HIP_CHECK(ctx, own_sums.alloc(ctx, ((size_t)oblocks / 1024 + 4) * sizeof(uint32_t)));
-            hipLaunchKernelGGL(owned_count_kernel, dim3(oblocks), dim3(GB_THREADS), 0, ctx->stream,
-                               ix->spts.as<float4>(), (uint32_t)ix->nvalid, a.q_begin, a.q_len,
-                               own_counts.as<uint32_t>());
-            PCRS_TRY(pcrs_launch_scan_u32(ctx, own_counts.as<uint32_t>(), oblocks,
-                                          own_sums.as<uint32_t>(), &counters[4]));
-            hipLaunchKernelGGL(owned_write_kernel, dim3(oblocks), dim3(GB_THREADS), 0, ctx->stream,
-                               ix->spts.as<float4>(), (uint32_t)ix->nvalid, a.q_begin, a.q_len,
-                               own_counts.as<uint32_t>(), listB);
+            SlotChoice ch{};
+            ch.q_begin = a.q_begin;
+            ch.q_len = a.q_len;
+            PCRS_TRY(choose_slots(ix, ch, listB, &counters[4]));
             a.qmode = 3;
             a.qlist = listB;
             a.qcount = &counters[4];
         }
+    } else if (q.only_list) {
+        // a list of the explicit queries (what another index could not certify)
+        a.qmode = 2;
+        a.nq = nq;
+        a.qlist = q.only_list;
+        a.qcount = q.only_count;
+        blocks1 = std::min(blocks1, (unsigned)ctx->num_cus * 8u);
     } else {
         a.qmode = 1;
         a.nq = nq;
@@ -2928,16 +3232,16 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     uint32_t *src = listB;
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     // stage 4: brute force over what is left
-    const int rc_bf = wave_does_all ? PCRS_OK
+    ix->left_list = src;  // what no stage of this index certified (answered below, unless the
+    ix->left_count = &counters[3];  // caller has another index to ask)
+    const int rc_bf = (wave_does_all || q.no_brute) ? PCRS_OK
                                     : pcrs_launch_knn_bf(ctx, ix->x, ix->y, ix->z, ix->m, q, out,
                                                          kneed, src, &counters[3], nq);
-    if (cov.p && rc_bf == PCRS_OK) {
+    if (cov.p && rc_bf == PCRS_OK) {  // (a caller that brings its own records solves them itself)
         const float *cqx = q.self ? ix->x + q.out_offset : q.qx;
         const float *cqy = q.self ? ix->y + q.out_offset : q.qy;
         const float *cqz = q.self ? ix->z + q.out_offset : q.qz;
-        hipLaunchKernelGGL(normals_from_cov_kernel, dim3((nq + GB_THREADS - 1) / GB_THREADS),
-                           dim3(GB_THREADS), 0, ctx->stream, nq, cov.as<float>(), cqx,
-                           cqy, cqz, out);
+        (void)pcrs_launch_normals_from_cov(ctx, nq, cov.as<float>(), cqx, cqy, cqz, out);
     }
     ctx->timing = timing_was;
     PCRS_TRY(rc_bf);

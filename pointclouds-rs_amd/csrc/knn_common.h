@@ -353,7 +353,7 @@ __device__ __forceinline__ void normal_from_cov(float c00, float c01, float c02,
 // order, so anything they write per query is scattered over the output, and a whole 32-byte
 // sector per query costs a fraction of seven separate 4-byte stores.  normals_from_cov_kernel
 // reads the records in index order and writes the caller's columns coalesced.
-constexpr size_t PCRS_REC_FLOATS = 8;
+constexpr size_t PCRS_REC_FLOATS = PCRS_REC_FLOATS_HOST;
 // A mean found before the record is written travels in the caller's copy of KnnOut
 // (rec_mean) and leaves with the record: two 16-byte stores fill the sector at once.
 __device__ __forceinline__ void store_mean(KnnOut &o, size_t qo, float mean) {

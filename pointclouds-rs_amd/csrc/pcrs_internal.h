@@ -16,6 +16,7 @@
 // (d2 = +inf, index = none): larger than every real key, and decodes to d2 = +inf
 #define PCRS_EMPTY_KEY 0x7F800000FFFFFFFFull
 #define PCRS_KMAX_REG 64  // largest neighbour list kept in registers
+#define PCRS_REC_FLOATS_HOST 8  // floats per query of the covariance records (knn_common.h)
 
 struct pcrs_ctx {
     int device = 0;
@@ -138,17 +139,50 @@ struct GridGeom {
     float cell, inv;    // cell edge and its reciprocal
     int nx, ny, nz;     // cells per axis
     float slack;        // absolute safety margin covering f32 rounding of cell assignment
+    // An index over a BOX of a cloud (one GPU's slab of a sharded cloud, a dense region given a
+    // finer grid of its own) leaves the points beyond the box out.  Where the cloud goes on behind
+    // a face of the box that face is "open": open_lo / open_hi hold its grid-relative coordinate
+    // (-inf / +inf for a face with nothing behind it), and no search may certify a result whose
+    // ball reaches across it.
+    float open_lo[3], open_hi[3];
 };
 
+// Which points of the columns an index takes in: finite, and lo[a] <= p[a] < hi[a] on every axis
+// (-inf / +inf: no limit on that side).
+struct BoxFilter {
+    float lo[3], hi[3];
+    __host__ __device__ bool unbounded() const {
+        return lo[0] == -__builtin_inff() && lo[1] == -__builtin_inff() && lo[2] == -__builtin_inff() &&
+               hi[0] == __builtin_inff() && hi[1] == __builtin_inff() && hi[2] == __builtin_inff();
+    }
+};
+inline BoxFilter pcrs_no_box() {
+    BoxFilter b;
+    for (int a = 0; a < 3; ++a) {
+        b.lo[a] = -__builtin_inff();
+        b.hi[a] = __builtin_inff();
+    }
+    return b;
+}
+
 struct pcrs_index {
+    ~pcrs_index();
     pcrs_ctx *ctx = nullptr;
     const float *x = nullptr, *y = nullptr, *z = nullptr;  // device columns (original order)
     size_t m = 0;
     DevBuf own_x, own_y, own_z;  // set when built from host memory
     int algo = PCRS_ALGO_BRUTE;  // resolved strategy (BRUTE or GRID)
+    uint32_t k_hint = 0;         // the list length the grid was sized for
+    // the part of the columns the grid holds (everything finite, by default)
+    BoxFilter box = pcrs_no_box();
+    // bounds that hold every point the grid takes and an upper limit of their number, from a
+    // caller that has just measured the cloud: the build then skips its own pass for them
+    bool have_bounds = false;
+    double bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
+    size_t bounds_n_upper = 0;
     // grid (algo == GRID)
     GridGeom g{};
-    size_t nvalid = 0;   // finite points
+    size_t nvalid = 0;   // points in the grid: finite and inside the box
     uint32_t ncell = 0;
     DevBuf cell_start;   // uint32 [ncell + 1] slot ranges of the cells (x-fastest cell order)
     DevBuf spts;         // float4 [nvalid] points sorted by cell: (x, y, z, original index bits)
@@ -159,6 +193,16 @@ struct pcrs_index {
     // other for the search after it, so no search starts with a fill command of its own.
     DevBuf counters;
     int counter_phase = 0;
+    // queries picked by pcrs_grid_select_box: their sorted slots (+ the count behind them)
+    DevBuf sel_list;
+    uint32_t sel_count = 0;
+    // what the last search left uncertified (device list of query positions and its length);
+    // valid until the next search on this index
+    const uint32_t *left_list = nullptr;
+    const uint32_t *left_count = nullptr;
+    // an index over the whole cloud, built on first need, for the queries an index over a box
+    // cannot certify (their neighbourhood reaches across an open face)
+    pcrs_index *whole = nullptr;
     // counters of the last query: read back lazily by pcrs_index_last_stats
     uint64_t stats[3] = {0, 0, 0};
     const uint32_t *stats_dev = nullptr;  // device counters [4]: failures after cube stages 1-4
@@ -204,6 +248,12 @@ struct KnnQuery {
     // device word that, when non-zero, turns the whole search into a no-op (an ICP iteration
     // queued behind the end of its loop)
     const uint32_t *skip_flag = nullptr;
+    // explicit queries only: answer just the listed ones (device list of positions in qx/qy/qz
+    // and its length), e.g. those another index left uncertified
+    const uint32_t *only_list = nullptr, *only_count = nullptr;
+    // leave what the grid stages cannot certify in the index's left_list instead of sending it to
+    // the brute-force kernel (the caller asks another index)
+    bool no_brute = false;
     // 1-NN searches of an ICP loop: `xform` (device, an IcpLoopState) holds a rigid increment that
     // is still to be applied to the queries; a search kernel that can do so applies it as it
     // loads each query, writes the moved point back to wx/wy/wz (the query columns, writable) and
@@ -290,6 +340,21 @@ int pcrs_grid_slot_bounds(pcrs_index *ix, uint32_t parts, size_t *bounds);
 int pcrs_grid_slot_slice(pcrs_index *ix, size_t begin, size_t count, float *ox, float *oy,
                          float *oz, uint32_t *perm);
 int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out, uint32_t kneed);
+int pcrs_grid_select_box(pcrs_index *ix, const BoxFilter &qbox, size_t *count);
+// what the cut measured on its way (nullable): the cloud's bounding box and the histogram of its
+// points along the cut axis, bin b = [hist_lo + b * hist_width, hist_lo + (b + 1) * hist_width)
+struct SlabMeasure {
+    double lo[3], hi[3];
+    float hist_lo = 0.0f, hist_width = 0.0f;
+    std::vector<uint32_t> hist;
+};
+int pcrs_slab_cuts(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t m,
+                   uint32_t parts, uint32_t k_hint, int *axis_out, float *cuts, float *halo,
+                   size_t *n_finite, SlabMeasure *measure = nullptr);
+int pcrs_grid_gather_selected(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm);
+// one thread per query: the oriented normal from the query's covariance record (and its mean)
+int pcrs_launch_normals_from_cov(pcrs_ctx *ctx, size_t nq, const float *cov, const float *qx,
+                                 const float *qy, const float *qz, const KnnOut &out);
 // consumer defaults for the non-finite queries of a self-query range (knn_bf.hip)
 int pcrs_launch_invalid_defaults(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,
                                  const KnnQuery &q, const KnnOut &out);

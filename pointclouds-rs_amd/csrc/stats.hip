@@ -28,6 +28,9 @@ constexpr int ST_CHUNK = 256;           // elements per chunk = one wave x 4
 constexpr int ST_PER_LANE = ST_CHUNK / 64;
 constexpr uint32_t ST_SAT = 1u << 30;   // saturation of composite increments (>= 2^24 means "left the binade")
 constexpr int ST_NO_BINADE = -1000;
+// The "binade" of a running sum that is still exactly zero: it stays zero over every element
+// that is zero (constant means give a variance pass of nothing but zeros).
+constexpr int ST_ZERO = -999;
 
 struct StatsScalars {
     float mu;
@@ -248,6 +251,10 @@ __device__ __forceinline__ Composite element_function(float x, int e) {
     Composite f;
     f.e = e;
     f.pad = 0;
+    if (e == ST_ZERO) {  // a sum of zero stays zero only over zeros
+        f.a0 = f.a1 = x == 0.0f ? 0u : ST_SAT;
+        return f;
+    }
     const uint32_t bits = __float_as_uint(x);
     const uint32_t ex = bits >> 23, mant = bits & 0x7FFFFFu;
     const uint32_t m = ex ? (mant | 0x800000u) : mant;  // subnormals have no hidden bit
@@ -276,6 +283,7 @@ __device__ __forceinline__ Composite element_function(float x, int e) {
 
 __device__ __forceinline__ int binade_of(float s) {
     const uint32_t b = __float_as_uint(s);
+    if (b == 0u) return ST_ZERO;
     const int ex = (int)((b >> 23) & 0xFFu);
     if (ex == 0 || ex == 255 || (b >> 31)) return ST_NO_BINADE;
     const int e = ex - 127;
@@ -306,8 +314,10 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
     const int pred = binade_of((float)cpre[chunk]);
     int binades[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) binades[j] = pred == ST_NO_BINADE ? ST_NO_BINADE : pred - j;
-    if (W == 4 && pred != ST_NO_BINADE) {
+    for (int j = 0; j < W; ++j)
+        binades[j] = pred == ST_NO_BINADE ? ST_NO_BINADE
+                                          : (pred == ST_ZERO ? (j == 0 ? ST_ZERO : ST_NO_BINADE) : pred - j);
+    if (W == 4 && pred != ST_NO_BINADE && pred != ST_ZERO) {
         const int emax = binade_of(__uint_as_float(sc->max_bits));
         const int cap = emax != ST_NO_BINADE ? emax + 25 : 100;
         const int top = min(pred + 1, cap);
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256) void chunk_composite_kernel(const float *mean,
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         int ej = binades[j];
-        if (ej != ST_NO_BINADE && (ej < -100 || ej > 100)) ej = ST_NO_BINADE;
+        if (ej != ST_NO_BINADE && ej != ST_ZERO && (ej < -100 || ej > 100)) ej = ST_NO_BINADE;
         Composite f;
         f.a0 = f.a1 = 0;
         f.e = ej;

@@ -129,6 +129,60 @@ class HipEngine:
                                                            vp, self._p(point), self._p(mean),
                                                            self._p(nx), self._p(ny), self._p(nz)))
 
+    # -- ownership by slabs of space: an index over the rank's slab plus a halo
+    def slab_cuts(self, x, y, z, parts, k_hint):
+        """(axis, cuts[parts + 1], halo, n_finite) of the cloud in the device columns x, y, z."""
+        axis = C.c_int()
+        cuts = (C.c_float * (parts + 1))()
+        halo = C.c_float()
+        nf = C.c_size_t()
+        self.ctx.check(self.lib.pcrs_slab_cuts_dev(self.ctx.handle, self._p(x), self._p(y), self._p(z),
+                                                   x.numel(), parts, k_hint, C.byref(axis), cuts,
+                                                   C.byref(halo), C.byref(nf)))
+        return int(axis.value), [float(c) for c in cuts], float(halo.value), int(nf.value)
+
+    def build_index_box(self, x, y, z, k_hint, box_lo, box_hi):
+        h = _V()
+        lo = (C.c_float * 3)(*box_lo)
+        hi = (C.c_float * 3)(*box_hi)
+        self.ctx.check(self.lib.pcrs_index_build_box_dev(self.ctx.handle, self._p(x), self._p(y),
+                                                         self._p(z), x.numel(), k_hint, lo, hi,
+                                                         C.byref(h)))
+        return h
+
+    def slab_index(self, x, y, z, k_hint, parts, part):
+        """Cut, index over slab `part` and its halo, selection of the slab's points, in one call:
+        (index, n_queries, axis) or (None, 0, axis) when the cloud has no slabs."""
+        h = _V()
+        n = C.c_size_t()
+        axis = C.c_int()
+        slab = (C.c_float * 2)()
+        self.ctx.check(self.lib.pcrs_slab_index_build_dev(self.ctx.handle, self._p(x), self._p(y),
+                                                          self._p(z), x.numel(), k_hint, parts, part,
+                                                          C.byref(h), C.byref(n), C.byref(axis), slab))
+        return (h if h.value else None), int(n.value), int(axis.value)
+
+    def select_box(self, index, q_lo, q_hi):
+        """Number of indexed points inside [q_lo, q_hi): the queries of sor_normals_selected.
+        None when the box holds too few points for a grid."""
+        n = C.c_size_t()
+        rc = self.lib.pcrs_index_select_box(index, (C.c_float * 3)(*q_lo), (C.c_float * 3)(*q_hi),
+                                            C.byref(n))
+        if rc == _ffi.PCRS_ERR_INVALID_ARG:
+            return None
+        self.ctx.check(rc)
+        return int(n.value)
+
+    def sor_normals_selected(self, index, k_sor, k_nrm, viewpoint, point, mean, nx, ny, nz):
+        """Returns how many of the selected queries the box could not certify (answered from an
+        index over the whole cloud)."""
+        vp = (C.c_float * 3)(*[float(v) for v in viewpoint])
+        esc = C.c_size_t()
+        self.ctx.check(self.lib.pcrs_sor_normals_selected_dev(index, k_sor, k_nrm, vp, self._p(point),
+                                                              self._p(mean), self._p(nx),
+                                                              self._p(ny), self._p(nz), C.byref(esc)))
+        return int(esc.value)
+
     def scatter(self, values, point, out):
         """out[point[i]] = values[i]"""
         self.ctx.check(self.lib.pcrs_scatter_f32_dev(self.ctx.handle, self._p(values),
@@ -308,6 +362,11 @@ class Collectives:
             else:
                 self.dist.all_reduce(t)
 
+    def all_reduce_min(self, t):
+        """In-place minimum of a small tensor over ranks."""
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+
     def barrier(self):
         if self.dist:
             self.dist.barrier()
@@ -338,8 +397,15 @@ def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
               for r in range(world)]
     begin, end = shard_range(n_total, world, rank)
     assert shard[0].numel() == end - begin, "shard length does not match its index range"
-    assert ownership in ("index", "cells")
+    assert ownership in ("index", "cells", "slabs")
     full = [coll.all_gather_var(torch, c, counts) for c in shard]
+    if ownership == "slabs":
+        res = _sor_normals_slabs(engine, coll, full, n_total, k_sor, std_mul, k_nrm, viewpoint,
+                                 outputs if outputs is not None else {}, want_stats)
+        if res is not None:
+            res.update(begin=begin, end=end)
+            return res
+        ownership = "index"  # no slabs to cut (non-finite points, a box too small for a grid)
     if outputs is None:
         outputs = {}
 
@@ -389,6 +455,58 @@ def sor_normals_sharded(engine, coll, shard, n_total, k_sor, std_mul, k_nrm,
             mean_full.zero_()
             engine.scatter(mean, point, mean_full)
             coll.all_reduce_sum(mean_full)
+        thr, ok, n_keep = engine.select(mean_full, std_mul, mean, keep)
+        if ok:
+            result["thr"] = thr
+            result["n_keep"] = n_keep
+    return result
+
+
+def _sor_normals_slabs(engine, coll, full, n_total, k_sor, std_mul, k_nrm, viewpoint, outputs,
+                       want_stats):
+    """ownership="slabs": the cloud is cut along its longest axis into one slab per rank (equal
+    point counts; a pure function of the replicated columns, so every rank derives the same cuts
+    without a collective).  A rank indexes only its slab plus a halo — not the whole cloud — and
+    answers the slab's points; the few queries whose neighbourhood reaches beyond the halo are
+    answered from an index over the whole cloud that is built only when there are any.  The means
+    travel as (point index, mean) pairs: all-gather, then every rank drops them into index order.
+    Returns None when the cloud cannot be cut this way."""
+    torch = engine.torch
+    world, rank = coll.world, coll.rank
+    k_hint = max(k_sor + 1 if k_sor else 0, k_nrm)
+    index, nq, axis = engine.slab_index(full[0], full[1], full[2], k_hint, world, rank)
+    try:
+        # every rank must take the same road: one without a grid sends all back to index ranges
+        ok = torch.tensor([0 if index is None else 1], dtype=torch.int32,
+                          device="cpu" if coll.stage else engine.device)
+        coll.all_reduce_min(ok)
+        if int(ok.item()) == 0:
+            return None
+
+        def buf(name, n, dtype="float32"):
+            t = outputs.get(name)
+            return t[:n] if t is not None and t.numel() >= n else engine.empty(n, dtype)
+
+        mean, keep, point = buf("mean", nq), buf("keep", nq, "uint8"), buf("point", nq, "int32")
+        nx = ny = nz = None
+        if k_nrm > 0:
+            nx, ny, nz = buf("nx", nq), buf("ny", nq), buf("nz", nq)
+        escalated = engine.sor_normals_selected(index, k_sor, k_nrm, viewpoint, point,
+                                                mean if k_sor else None, nx, ny, nz)
+        stats = engine.index_stats(index) if want_stats else None
+    finally:
+        if index is not None:
+            engine.destroy_index(index)
+    result = dict(mean=mean, keep=keep, nx=nx, ny=ny, nz=nz, thr=math.nan, n_keep=0, stats=stats,
+                  point=point, ownership="slabs", escalated=escalated, slab_axis=axis)
+    if k_sor:
+        own = torch.tensor([nq], dtype=torch.int64, device="cpu" if coll.stage else engine.device)
+        all_counts = [int(c) for c in coll.all_gather_var(torch, own, [1] * world).tolist()]
+        assert sum(all_counts) == n_total, "the slabs do not partition the cloud"
+        points_all = coll.all_gather_var(torch, point, all_counts)
+        means_all = coll.all_gather_var(torch, mean, all_counts)
+        mean_full = buf("mean_by_index", n_total)
+        engine.scatter(means_all, points_all, mean_full)  # every index exactly once: no zeroing
         thr, ok, n_keep = engine.select(mean_full, std_mul, mean, keep)
         if ok:
             result["thr"] = thr

@@ -9,7 +9,7 @@ from pointclouds_rs import synth
 from pointclouds_rs.dist import HipEngine
 
 eng = HipEngine(0)
-mode = sys.argv[1] if len(sys.argv) > 1 else "index"  # "index" or "cells"
+mode = sys.argv[1] if len(sys.argv) > 1 else "index"  # "index", "cells" or "slabs"
 worlds = [int(sys.argv[2])] if len(sys.argv) > 2 else [1, 2, 4, 8]
 for world in worlds:
     n = world * 1_000_000
@@ -26,7 +26,22 @@ for world in worlds:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ix = eng.build_index(*cols, 17)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        if mode == "index":
+        if mode == "slabs":
+            # the slab of rank `world // 2` (halo on both sides) and its index instead of `ix`
+            eng.destroy_index(ix)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ix, c, axis = eng.slab_index(*cols, 17, world, world // 2)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            if c > mean.numel():
+                mean = eng.empty(c); nx = eng.empty(c); ny = eng.empty(c); nz = eng.empty(c)
+                keep = eng.empty(c, "uint8"); point = eng.empty(c, "int32")
+            esc = eng.sor_normals_selected(ix, 16, 16, (0.0, 0.0, 0.0), point[:c], mean[:c], nx[:c],
+                                           ny[:c], nz[:c])
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            # every rank's (point, mean) pairs arrive by all-gather; dropping them into index order
+            # is this rank's part (the pairs of the other ranks are made up)
+            eng.scatter(gathered, point_full, mean_full)
+        elif mode == "index":
             eng.sor_normals_range(ix, 0, nq, 16, 16, (0.0, 0.0, 0.0), mean, nx, ny, nz)
             torch.cuda.synchronize(); t2 = time.perf_counter()
             mean_full[:nq] = mean
@@ -42,9 +57,11 @@ for world in worlds:
             mean_full.zero_()  # the sum over ranks of these vectors is the collective's part
             eng.scatter(mean[:c], point[:c], mean_full)
             mean_full += gathered  # stands in for the other ranks' means
-        thr, ok, nk = eng.select(mean_full, 1.0, mean, keep)
+        thr, ok, nk = eng.select(mean_full, 1.0, mean[:c] if mode == "slabs" else mean, keep[:c] if mode == "slabs" else keep)
         torch.cuda.synchronize(); t3 = time.perf_counter()
         eng.destroy_index(ix)
         ts.append((t1 - t0, t2 - t1, t3 - t2))
     b, s, st = np.median(np.array(ts[1:]), 0) * 1e3
+    if mode == "slabs":
+        print(f"   slab of rank {world // 2}: {c} queries, {esc} escalated, axis {axis}", flush=True)
     print(f"{mode} world {world}: build {b:.3f} ms  search(1M of {n}) {s:.3f} ms  stats+mask {st:.3f} ms  total {b+s+st:.3f} ms", flush=True)

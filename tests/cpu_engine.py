@@ -73,6 +73,69 @@ class CpuEngine:
             for dst, src in zip((nx, ny, nz), n):
                 dst.copy_(torch.from_numpy(src[sel].copy()))
 
+    # ---- ownership by slabs of space
+    def slab_cuts(self, x, y, z, parts, k_hint):
+        X = np.stack([x.numpy(), y.numpy(), z.numpy()], 1)
+        fin = np.isfinite(X).all(axis=1)
+        n_finite = int(fin.sum())
+        cuts = [-np.inf] + [np.inf] * parts
+        if n_finite == 0:
+            return 0, cuts, 0.0, 0
+        P = X[fin]
+        lo, hi = P.min(axis=0).astype(np.float64), P.max(axis=0).astype(np.float64)
+        ext = hi - lo
+        axis = int(np.argmax(ext))
+        if not ext[axis] > 0:
+            return axis, cuts, 0.0, n_finite
+        vol = float(np.prod(np.maximum(ext, 1e-3 * ext[axis])))
+        halo = 3.0 * (vol * float(k_hint or 16) / n_finite) ** (1.0 / 3.0)
+        v = np.sort(P[:, axis])
+        for r in range(1, parts):  # equal counts; points at the same coordinate stay together
+            cuts[r] = float(v[r * n_finite // parts])
+        return axis, cuts, float(halo), n_finite
+
+    def slab_index(self, x, y, z, k_hint, parts, part):
+        axis, cuts, halo, n_finite = self.slab_cuts(x, y, z, parts, k_hint)
+        if n_finite != x.numel() or not np.isfinite(cuts[1:parts]).all():
+            return None, 0, axis
+        inf = float("inf")
+        lo, hi, qlo, qhi = [-inf] * 3, [inf] * 3, [-inf] * 3, [inf] * 3
+        qlo[axis], qhi[axis] = cuts[part], cuts[part + 1]
+        lo[axis] = cuts[part] - halo if part > 0 else -inf
+        hi[axis] = cuts[part + 1] + halo if part + 1 < parts else inf
+        index = self.build_index_box(x, y, z, k_hint, lo, hi)
+        n = self.select_box(index, qlo, qhi)
+        return (None, 0, axis) if n is None else (index, n, axis)
+
+    def build_index_box(self, x, y, z, k_hint, box_lo, box_hi):
+        return dict(cols=(x.numpy(), y.numpy(), z.numpy()), lo=np.array(box_lo), hi=np.array(box_hi),
+                    sel=None)
+
+    def select_box(self, index, q_lo, q_hi):
+        X = np.stack(index["cols"], 1)
+        inside = np.isfinite(X).all(axis=1)
+        boxed = inside.copy()
+        for a in range(3):
+            inside &= (X[:, a] >= np.float32(q_lo[a])) & (X[:, a] < np.float32(q_hi[a]))
+            boxed &= (X[:, a] >= np.float32(index["lo"][a])) & (X[:, a] < np.float32(index["hi"][a]))
+        if boxed.sum() < 64:
+            return None  # too few points for a grid
+        sel = np.flatnonzero(inside)
+        index["sel"] = sel[np.argsort(X[sel, 0], kind="stable")]  # some spatial order
+        return len(sel)
+
+    def sor_normals_selected(self, index, k_sor, k_nrm, viewpoint, point, mean, nx, ny, nz):
+        x, y, z = index["cols"]
+        sel = index["sel"]
+        point.copy_(torch.from_numpy(sel.astype(np.uint32).view(np.int32).copy()))
+        if mean is not None:
+            mean.copy_(torch.from_numpy(self.o.sor_mean_dist(x, y, z, k_sor, algo=1)[sel].copy()))
+        if nx is not None:
+            n = self.o.normals(x, y, z, k_nrm, viewpoint, algo=1)
+            for dst, src in zip((nx, ny, nz), n):
+                dst.copy_(torch.from_numpy(src[sel].copy()))
+        return 0
+
     def scatter(self, values, point, out):
         out.numpy()[point.numpy().view(np.uint32)] = values.numpy()
 

@@ -52,6 +52,18 @@ def _worker(rank, world, port, n_total, q):
                         point=rc["point"].numpy().view(np.uint32).copy(),
                         keep=rc["keep"].numpy().copy(), mean=rc["mean"].numpy().copy(),
                         nx=rc["nx"].numpy().copy())
+    # ownership by slabs of space (each rank indexes its slab plus a halo only)
+    rs = sor_normals_sharded(eng, coll, shard, n_total, 8, 1.0, 8, ownership="slabs")
+    out["slabs"] = dict(ownership=rs["ownership"], thr=rs["thr"], n_keep=rs["n_keep"],
+                        point=rs["point"].numpy().view(np.uint32).copy(),
+                        keep=rs["keep"].numpy().copy(), mean=rs["mean"].numpy().copy(),
+                        nx=rs["nx"].numpy().copy())
+    # a cloud with a non-finite point has no slabs: every rank falls back to index ranges
+    xb = x.copy()
+    xb[5] = np.nan
+    rb = sor_normals_sharded(eng, coll, [eng.from_numpy(c[b:e]) for c in (xb, y, z)], n_total, 8, 1.0,
+                             0, ownership="slabs")
+    out["slabs_fallback"] = rb["ownership"]
     # sharded ICP (point-to-plane), source split over the ranks, target replicated
     tgt = synth.hemisphere(1500, 99, 5.0)
     tn = o.normals(*tgt, 12, algo=1)
@@ -105,13 +117,18 @@ def test_sharded_matches_single_process(oracle):
     pts = np.concatenate([o["cells"]["point"] for o in outs])
     assert np.array_equal(np.sort(pts), np.arange(n_total, dtype=np.uint32))
     assert sum(o["cells"]["n_keep"] for o in outs) == n_keep
-    for o in outs:
-        c = o["cells"]
-        assert c["ownership"] == "cells" and len(c["point"]) > 0
-        assert np.float32(c["thr"]) == np.float32(thr)
-        assert np.array_equal(c["mean"], mean[c["point"]])
-        assert np.array_equal(c["keep"].astype(bool), keep[c["point"]])
-        assert np.array_equal(c["nx"], nx[c["point"]])
+    for own in ("cells", "slabs"):
+        pts = np.concatenate([o[own]["point"] for o in outs])
+        assert np.array_equal(np.sort(pts), np.arange(n_total, dtype=np.uint32))
+        assert sum(o[own]["n_keep"] for o in outs) == n_keep
+        for o in outs:
+            c = o[own]
+            assert c["ownership"] == own and len(c["point"]) > 0
+            assert np.float32(c["thr"]) == np.float32(thr)
+            assert np.array_equal(c["mean"], mean[c["point"]])
+            assert np.array_equal(c["keep"].astype(bool), keep[c["point"]])
+            assert np.array_equal(c["nx"], nx[c["point"]])
+    assert all(o["slabs_fallback"] == "index" for o in outs)
     # ICP: both ranks hold the same transform, equal to the single-process oracle run
     tgt = synth.hemisphere(1500, 99, 5.0)
     tn = oracle.normals(*tgt, 12, algo=1)

@@ -49,10 +49,11 @@ def _worker(rank, world, port, q, icp_inputs):
     b, e = shard_range(n_total, world, rank)
     shard = [eng.from_numpy(c[b:e]) for c in (x, y, z)]
     out = dict(rank=rank, begin=b, end=e)
-    for own in ("index", "cells"):
+    for own in ("index", "cells", "slabs"):
         r = sor_normals_sharded(eng, coll, shard, n_total, 16, 1.0, 16, ownership=own)
         torch.cuda.synchronize()
         out[own] = dict(ownership=r["ownership"], thr=r["thr"], n_keep=r["n_keep"],
+                        escalated=r.get("escalated", 0),
                         point=None if r["point"] is None else r["point"].cpu().numpy().view(np.uint32).copy(),
                         keep=r["keep"].cpu().numpy().copy(), mean=r["mean"].cpu().numpy().copy(),
                         normals=[r[c].cpu().numpy().copy() for c in ("nx", "ny", "nz")])
@@ -126,7 +127,7 @@ def test_two_ranks_both_ownerships(oracle, tmp_path):
     n_total = len(x)
     keep, n_keep, thr, mean = oracle.sor(x, y, z, 16, 1.0, algo=1)
     rn = oracle.normals(x, y, z, 16, algo=1)
-    for own in ("index", "cells"):
+    for own in ("index", "cells", "slabs"):
         assert sum(o[own]["n_keep"] for o in outs) == n_keep
         pts = []
         for o in outs:

@@ -889,3 +889,127 @@ def test_one_walk_kernel_consumers(hip, oracle):
     # which both sides resolve alike: the covariance sums are then the same numbers)
     for a, b in zip(nrm, rnrm):
         assert float(np.abs(a - b).max()) <= 1e-5
+
+
+def _bit_equal(a, b):
+    return np.array_equal(np.asarray(a, dtype=F).view(np.uint32), np.asarray(b, dtype=F).view(np.uint32))
+
+
+def test_cloud_of_one_repeated_point(hip, oracle):
+    """Every point in one place (kiddo panics on such a cloud; here it must be neither wrong nor
+    slow): a grid of one cell, the lane kernel's zero-distance shortcut for SOR and normals,
+    the exact stages for lists.  The oracle's (d2, descending index) order defines the lists."""
+    import time
+
+    n = 12_000
+    x, y, z = np.full(n, 1.5, F), np.full(n, -2.25, F), np.full(n, 3.0, F)
+    vp = (0.0, 0.0, 10.0)
+    keep, n_keep, thr, mean = hip.sor(x, y, z, 16, 1.0)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, 16, 1.0, algo=0)
+    assert _bit_equal(mean, rmean) and n_keep == rn == n and np.array_equal(keep, rkeep)
+    assert _bit_equal(thr, rthr) and thr == 0.0
+    got = hip.normals(x, y, z, 16, vp)
+    ref = oracle.normals(x, y, z, 16, vp, algo=0)
+    for g, r in zip(got, ref):
+        assert _bit_equal(g, r)
+    keep2, nk2, thr2, nrm2 = hip.sor_normals(x, y, z, 16, 1.0, 16, vp)
+    assert nk2 == n and thr2 == 0.0 and all(_bit_equal(g, r) for g, r in zip(nrm2, ref))
+    # lists: the k largest indices, all at distance zero
+    ix = hip.Index(x, y, z, k_hint=5)
+    idx, dist, cnt = ix.knn(x[:300], y[:300], z[:300], 5)
+    ix.close()
+    ridx, rdist, _, rcnt = oracle.knn(x, y, z, x[:300], y[:300], z[:300], 5, algo=0)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt) and _bit_equal(dist, rdist)
+    assert list(idx[0]) == [n - 1, n - 2, n - 3, n - 4, n - 5]
+    # the size that used to take 0.7 s (every query compared with every point): analytic answer
+    n = 100_000
+    x, y, z = np.full(n, 1.0, F), np.full(n, 2.0, F), np.full(n, 3.0, F)
+    hip.sor(x, y, z, 16, 1.0)
+    t0 = time.perf_counter()
+    keep, n_keep, thr, mean = hip.sor(x, y, z, 16, 1.0)
+    dt = time.perf_counter() - t0
+    assert n_keep == n and thr == 0.0 and not mean.any()
+    assert dt < 0.05, f"{dt * 1e3:.1f} ms"
+    got = hip.normals(x, y, z, 16, vp)
+    assert not got[0].any() and not got[1].any() and np.all(got[2] == 1.0)
+
+
+def test_half_the_cloud_is_one_point(hip, oracle):
+    """10 K uniform points and 10 K copies of one of them, shuffled: the copies' cell holds more
+    points than a lane walks (they are answered from the start of their cell), their neighbours'
+    cubes go to the wave-per-query kernel."""
+    ux, uy, uz = gen.uniform_cloud(10_000, 3)
+    x = np.concatenate([ux, np.full(10_000, ux[17], F)])
+    y = np.concatenate([uy, np.full(10_000, uy[17], F)])
+    z = np.concatenate([uz, np.full(10_000, uz[17], F)])
+    p = np.random.default_rng(1).permutation(len(x))
+    x, y, z = x[p], y[p], z[p]
+    vp = (50.0, 50.0, 500.0)
+    for k in (16, 4):
+        keep, n_keep, thr, mean = hip.sor(x, y, z, k, 1.0)
+        rkeep, rn, rthr, rmean = oracle.sor(x, y, z, k, 1.0, algo=1)
+        assert _bit_equal(mean, rmean), k
+        assert _bit_equal(thr, rthr) and n_keep == rn and np.array_equal(keep, rkeep)
+        keep2, nk2, thr2, nrm = hip.sor_normals(x, y, z, k, 1.0, k, vp)
+        ref = oracle.normals(x, y, z, k, vp, algo=1)
+        assert nk2 == rn and _bit_equal(thr2, rthr)
+        assert normals_close(nrm, ref, 1e-5).all()
+    ix = hip.Index(x, y, z, k_hint=17)
+    q = slice(0, 400)
+    idx, dist, cnt = ix.knn(x[q], y[q], z[q], 17)
+    ix.close()
+    ridx, rdist, _, rcnt = oracle.knn(x, y, z, x[q], y[q], z[q], 17, algo=0)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt) and _bit_equal(dist, rdist)
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_slab_indexes_partition_the_cloud_and_match_the_oracle(oracle, world):
+    """What each rank of a run with ownership by slabs computes, rank after rank on one GPU: the
+    cuts, an index over the slab plus a halo, the slab's queries.  The slabs must partition the
+    cloud and every answer must be the oracle's for the whole cloud -- for the points whose
+    neighbours lie across a cut (in the halo) and for those whose neighbourhood reaches beyond the
+    halo (answered from the index over the whole cloud: forced here by a second run with a halo a
+    hundred times too small)."""
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine.shared(0)
+    x, y, z = gen.kitti_scene(5, 40000, 3000, 600)   # a ground plane, objects, strays
+    n, k = len(x), 16
+    cols = [eng.from_numpy(c) for c in (x, y, z)]
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, k, 1.0, algo=1)
+    rnrm = oracle.normals(x, y, z, k, (0.0, 0.0, 1.7), algo=1)
+    axis, cuts, halo, n_finite = eng.slab_cuts(*cols, world, k + 1)
+    assert n_finite == n and cuts[0] == -np.inf and cuts[-1] == np.inf
+    assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+    inf = float("inf")
+    for shrink in (1.0, 0.01):
+        seen = np.zeros(n, dtype=np.int32)
+        escalated = 0
+        for r in range(world):
+            lo, hi, qlo, qhi = [-inf] * 3, [inf] * 3, [-inf] * 3, [inf] * 3
+            qlo[axis], qhi[axis] = cuts[r], cuts[r + 1]
+            lo[axis] = cuts[r] - halo * shrink if r > 0 else -inf
+            hi[axis] = cuts[r + 1] + halo * shrink if r + 1 < world else inf
+            ix = eng.build_index_box(*cols, k + 1, lo, hi)
+            nq = eng.select_box(ix, qlo, qhi)
+            assert nq is not None and abs(nq - n / world) < 0.02 * n + 64
+            if shrink == 1.0:  # the three calls in one give the same slab
+                ix2, nq2, axis2 = eng.slab_index(*cols, k + 1, world, r)
+                assert ix2 is not None and nq2 == nq and axis2 == axis
+                p2 = eng.empty(nq2, "int32"); m2 = eng.empty(nq2)
+                eng.sor_normals_selected(ix2, k, 0, (0.0, 0.0, 0.0), p2, m2, None, None, None)
+                eng.destroy_index(ix2)
+                pt2 = p2.cpu().numpy().view(np.uint32)
+                assert np.array_equal(m2.cpu().numpy().view(np.uint32), rmean[pt2].view(np.uint32))
+            point = eng.empty(nq, "int32"); mean = eng.empty(nq)
+            nx = eng.empty(nq); ny = eng.empty(nq); nz = eng.empty(nq)
+            escalated += eng.sor_normals_selected(ix, k, k, (0.0, 0.0, 1.7), point, mean, nx, ny, nz)
+            eng.destroy_index(ix)
+            pt = point.cpu().numpy().view(np.uint32)
+            seen[pt] += 1
+            assert np.array_equal(mean.cpu().numpy().view(np.uint32), rmean[pt].view(np.uint32)), (world, r, shrink)
+            got = [t.cpu().numpy() for t in (nx, ny, nz)]
+            assert normals_close(got, [c[pt] for c in rnrm], 1e-5).all()
+        assert (seen == 1).all()
+        if shrink < 1.0:
+            assert escalated > 0  # the small halo does send queries to the whole-cloud index

@@ -203,10 +203,10 @@ def run_sor_normals(args):
     full_host = cols if (rank == 0 and world == 1) else None
     shard = [engine.from_numpy(c) for c in cols]
     nq = end - begin
-    # With several ranks each one answers a run of whole cells of the replicated index (a compact
-    # region of space) instead of the scattered points it was handed; the runs follow the cell
-    # boundaries, so the buffers leave room for a little imbalance.
-    ownership = "cells" if world > 1 else "index"
+    # With several ranks each one indexes and answers a slab of space (equal point counts, cut along
+    # the cloud's longest axis) instead of the scattered points it was handed; the cuts fall on the
+    # edges of histogram bins, so the buffers leave room for a little imbalance.
+    ownership = "slabs" if world > 1 else "index"
     cap = nq if world == 1 else nq + nq // 8 + 65536
     outputs = dict(mean=engine.empty(cap), keep=engine.empty(cap, "uint8"), nx=engine.empty(cap),
                    ny=engine.empty(cap), nz=engine.empty(cap))

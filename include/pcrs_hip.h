@@ -340,6 +340,20 @@ int pcrs_slab_index_build_dev(pcrs_ctx *ctx, const float *dx, const float *dy, c
                               size_t m, uint32_t k_hint, uint32_t parts, uint32_t part,
                               pcrs_index **out, size_t *n_queries, int *axis, float slab[2]);
 
+/* The way back to index order for results a process computed for arbitrary points of a sharded
+ * cloud (no counterpart in the reference): the index range [0, n_total) is divided among `world`
+ * processes as contiguous ranges (the first n_total % world one longer, as pointclouds_rs.dist
+ * shard_range has it).  pcrs_route_pairs_dev buckets n (point index, value) pairs by the owner
+ * of the index: dsend_point / dsend_values hold the buckets in rank order, counts[world] (host)
+ * their sizes -- the send side of an all-to-all; waits for the stream once.
+ * pcrs_scatter_range_f32_dev drops received pairs into the owner's range:
+ * dout[dpoint[i] - first] = dvalues[i]. */
+int pcrs_route_pairs_dev(pcrs_ctx *ctx, const uint32_t *dpoint, const float *dvalues, size_t n,
+                         size_t n_total, uint32_t world, uint32_t *dsend_point, float *dsend_values,
+                         size_t *counts);
+int pcrs_scatter_range_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dpoint,
+                               size_t n, size_t first, float *dout);
+
 /* estimate_normals_with_viewpoint on host buffers.  k == 0 or n == 0 writes
  * nothing (the reference returns empty vectors, estimate.rs:25-31). */
 int pcrs_normals(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,

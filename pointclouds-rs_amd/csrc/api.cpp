@@ -1180,6 +1180,28 @@ int pcrs_scatter_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dp
     return pcrs_on_exception(ctx);
 }
 
+int pcrs_route_pairs_dev(pcrs_ctx *ctx, const uint32_t *dpoint, const float *dvalues, size_t n,
+                         size_t n_total, uint32_t world, uint32_t *dsend_point, float *dsend_values,
+                         size_t *counts) try {
+    PCRS_TRY(bind_device(ctx));
+    if (!counts || (n && (!dpoint || !dvalues || !dsend_point || !dsend_values)))
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    return pcrs_launch_route_pairs(ctx, dpoint, dvalues, n, n_total, world, dsend_point,
+                                   dsend_values, counts);
+} catch (...) {
+    return pcrs_on_exception(ctx);
+}
+
+int pcrs_scatter_range_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dpoint,
+                               size_t n, size_t first, float *dout) try {
+    PCRS_TRY(bind_device(ctx));
+    if (n && (!dvalues || !dpoint || !dout)) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    if (first >= 0xFFFFFFFFull) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "range start too large");
+    return pcrs_launch_scatter_offset(ctx, dvalues, dpoint, n, (uint32_t)first, dout);
+} catch (...) {
+    return pcrs_on_exception(ctx);
+}
+
 int pcrs_sor_mean_dist_dev(pcrs_index *index, size_t q_begin, size_t q_count, uint32_t k,
                            float *dmean) try {
     if (!dmean) return PCRS_ERR_INVALID_ARG;

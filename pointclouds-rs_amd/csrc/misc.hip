@@ -330,6 +330,55 @@ __global__ __launch_bounds__(256) void scatter_perm_kernel(const float *in, cons
     if (i < n) out[perm[i]] = in[i];
 }
 
+// (point index, value) pairs bucketed by the rank that owns the index under the partition of
+// [0, n_total) into `world` contiguous ranges (the first `rem` ranges one longer): the send side
+// of an all-to-all that takes every result to the owner of its index range.
+constexpr int ROUTE_MAX_WORLD = 64;
+struct RouteSplit {
+    uint32_t base, rem, world;  // range r = [r * base + min(r, rem), ...), length base + (r < rem)
+};
+__device__ __forceinline__ uint32_t route_dest(const RouteSplit &sp, uint32_t idx) {
+    const uint32_t big = sp.rem * (sp.base + 1u);  // indices below this lie in the longer ranges
+    return idx < big ? idx / (sp.base + 1u) : sp.rem + (idx - big) / (sp.base ? sp.base : 1u);
+}
+__global__ __launch_bounds__(256) void route_count_kernel(const uint32_t *point, size_t n,
+                                                          RouteSplit sp, uint32_t *counts) {
+    __shared__ uint32_t h[ROUTE_MAX_WORLD];
+    if (threadIdx.x < ROUTE_MAX_WORLD) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        atomicAdd(&h[route_dest(sp, point[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < sp.world && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+// cursors[d] starts at the first send slot of destination d; a block reserves room for its
+// pairs of every destination with one atomic each
+__global__ __launch_bounds__(256) void route_scatter_kernel(const uint32_t *point, const float *value,
+                                                            size_t n, RouteSplit sp, uint32_t *cursors,
+                                                            uint32_t *send_point, float *send_value) {
+    __shared__ uint32_t h[ROUTE_MAX_WORLD], at[ROUTE_MAX_WORLD];
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t b = (size_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    if (threadIdx.x < ROUTE_MAX_WORLD) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = b + threadIdx.x; i < e; i += 256) atomicAdd(&h[route_dest(sp, point[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < sp.world) at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], h[threadIdx.x]) : 0u;
+    __syncthreads();
+    for (size_t i = b + threadIdx.x; i < e; i += 256) {
+        const uint32_t p = point[i];
+        const uint32_t slot = atomicAdd(&at[route_dest(sp, p)], 1u);
+        send_point[slot] = p;
+        send_value[slot] = value[i];
+    }
+}
+// out[point[i] - first] = value[i]
+__global__ __launch_bounds__(256) void scatter_offset_kernel(const float *in, const uint32_t *point,
+                                                             size_t n, uint32_t first, float *out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[point[i] - first] = in[i];
+}
+
 // A few words from device memory straight into pinned host memory: a kernel of one wave costs
 // less than a copy command, and the host then only waits for the stream.
 __global__ void publish_words_kernel(const uint32_t *src, uint32_t *host_dst, uint32_t nwords) {
@@ -352,6 +401,57 @@ int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *per
     if (n == 0) return PCRS_OK;
     hipLaunchKernelGGL(scatter_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        ctx->stream, in, perm, n, out);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_scatter_offset(pcrs_ctx *ctx, const float *in, const uint32_t *point, size_t n,
+                               uint32_t first, float *out) {
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(scatter_offset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, in, point, n, first, out);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// Buckets n (point, value) pairs by the owner of the point's index range; counts[world] (host)
+// receives the bucket sizes, the send arrays hold the buckets in rank order.  Waits for the
+// stream once (the sizes are the split of the all-to-all that follows).
+int pcrs_launch_route_pairs(pcrs_ctx *ctx, const uint32_t *point, const float *value, size_t n,
+                            size_t n_total, uint32_t world, uint32_t *send_point, float *send_value,
+                            size_t *counts) {
+    if (world == 0 || world > ROUTE_MAX_WORLD)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "1 to %d ranks", ROUTE_MAX_WORLD);
+    if (n_total >= 0xFFFFFFFFull || n > n_total)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
+    if (n == 0) return PCRS_OK;
+    RouteSplit sp;
+    sp.world = world;
+    sp.base = (uint32_t)(n_total / world);
+    sp.rem = (uint32_t)(n_total % world);
+    DevBuf d;
+    PCRS_HIP_CHECK(ctx, d.alloc(ctx, 2 * ROUTE_MAX_WORLD * sizeof(uint32_t)));
+    uint32_t *d_counts = d.as<uint32_t>(), *d_cursors = d_counts + ROUTE_MAX_WORLD;
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, ROUTE_MAX_WORLD * sizeof(uint32_t), ctx->stream));
+    const unsigned blocks = stream_grid(ctx, n, 256);
+    hipLaunchKernelGGL(route_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, point, n, sp, d_counts);
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, ROUTE_MAX_WORLD * sizeof(uint32_t), &pin));
+    PCRS_TRY(pcrs_launch_publish(ctx, d_counts, pin, ROUTE_MAX_WORLD * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(pin);
+    uint32_t cursors[ROUTE_MAX_WORLD] = {0};
+    uint32_t run = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        counts[r] = h[r];
+        cursors[r] = run;
+        run += h[r];
+    }
+    PCRS_HIP_CHECK(ctx, hipMemcpyAsync(d_cursors, cursors, ROUTE_MAX_WORLD * sizeof(uint32_t),
+                                       hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(route_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, point, value, n,
+                       sp, d_cursors, send_point, send_value);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

@@ -368,6 +368,13 @@ int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint
 int pcrs_launch_publish(pcrs_ctx *ctx, const void *d_src, void *pinned_dst, size_t bytes);
 int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *perm, size_t n,
                              float *out);
+// out[point[i] - first] = in[i]
+int pcrs_launch_scatter_offset(pcrs_ctx *ctx, const float *in, const uint32_t *point, size_t n,
+                               uint32_t first, float *out);
+// (point, value) pairs bucketed by the owner of the point's index range (see misc.hip)
+int pcrs_launch_route_pairs(pcrs_ctx *ctx, const uint32_t *point, const float *value, size_t n,
+                            size_t n_total, uint32_t world, uint32_t *send_point, float *send_value,
+                            size_t *counts);
 int pcrs_launch_transform(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                           const float rot[9], const float t[3], float *ox, float *oy, float *oz);
 int pcrs_launch_radius_count(pcrs_ctx *ctx, const float *rx, const float *ry, const float *rz,

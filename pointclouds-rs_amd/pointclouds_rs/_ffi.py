@@ -91,6 +91,8 @@ SIGNATURES = {
     "pcrs_sor_normals_slots_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32,
                                              c_float_p, _V, _V, _V, _V, _V]),
     "pcrs_scatter_f32_dev": (C.c_int, [_V, _V, _V, C.c_size_t, _V]),
+    "pcrs_route_pairs_dev": (C.c_int, [_V, _V, _V, C.c_size_t, C.c_size_t, C.c_uint32, _V, _V, c_size_p]),
+    "pcrs_scatter_range_f32_dev": (C.c_int, [_V, _V, _V, C.c_size_t, C.c_size_t, _V]),
     "pcrs_slab_cuts_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_int),
                                                   c_float_p, c_float_p, c_size_p]),
     "pcrs_index_build_box_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, c_float_p, c_float_p,

@@ -183,6 +183,21 @@ class HipEngine:
                                                               self._p(ny), self._p(nz), C.byref(esc)))
         return int(esc.value)
 
+    def route_pairs(self, point, values, n_total, world, send_point, send_values):
+        """Buckets the (point, value) pairs by the rank that owns the point's index range; returns
+        the bucket sizes (the send buffers then hold the buckets in rank order)."""
+        counts = (C.c_size_t * world)()
+        self.ctx.check(self.lib.pcrs_route_pairs_dev(self.ctx.handle, self._p(point), self._p(values),
+                                                     point.numel(), n_total, world,
+                                                     self._p(send_point), self._p(send_values), counts))
+        return [int(c) for c in counts]
+
+    def scatter_range(self, values, point, first, out):
+        """out[point[i] - first] = values[i]"""
+        self.ctx.check(self.lib.pcrs_scatter_range_f32_dev(self.ctx.handle, self._p(values),
+                                                           self._p(point), values.numel(), first,
+                                                           self._p(out)))
+
     def scatter(self, values, point, out):
         """out[point[i]] = values[i]"""
         self.ctx.check(self.lib.pcrs_scatter_f32_dev(self.ctx.handle, self._p(values),
@@ -362,6 +377,42 @@ class Collectives:
             else:
                 self.dist.all_reduce(t)
 
+    def all_to_all_var(self, torch, send, send_counts, recv_counts=None):
+        """send holds world buckets in rank order (sizes send_counts); bucket r goes to rank r.
+        Returns (what the ranks sent here, concatenated in rank order; its per-rank sizes)."""
+        if self.world == 1:
+            return send[: send_counts[0]], list(send_counts)
+        if self.stage and send.device.type != "cpu":
+            out, rc = self.all_to_all_var(torch, send.cpu(), send_counts, recv_counts)
+            return out.to(send.device), rc
+        if recv_counts is None:  # every rank learns what the others send it
+            m = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+            allm = torch.empty(self.world * self.world, dtype=torch.int64, device=send.device)
+            self.dist.all_gather_into_tensor(allm, m)
+            recv_counts = [int(v) for v in allm.view(self.world, self.world)[:, self.rank].tolist()]
+        total = sum(send_counts)
+        send = send[:total].contiguous()
+        if self.dist.get_backend() == "nccl":
+            out = torch.empty(sum(recv_counts), dtype=send.dtype, device=send.device)
+            self.dist.all_to_all_single(out, send, list(recv_counts), list(send_counts))
+            return out, list(recv_counts)
+        # a backend without all-to-all (gloo): everybody's buckets are gathered and each rank
+        # picks its own out of them
+        totals = torch.tensor([total], dtype=torch.int64)
+        all_totals = [torch.empty_like(totals) for _ in range(self.world)]
+        self.dist.all_gather(all_totals, totals)
+        all_totals = [int(t.item()) for t in all_totals]
+        everything = self.all_gather_var(torch, send, all_totals)
+        m = torch.tensor(send_counts, dtype=torch.int64)
+        allm = [torch.empty_like(m) for _ in range(self.world)]
+        self.dist.all_gather(allm, m)
+        parts, base = [], 0
+        for r in range(self.world):
+            off = base + int(allm[r][: self.rank].sum().item())
+            parts.append(everything[off: off + int(allm[r][self.rank].item())])
+            base += all_totals[r]
+        return torch.cat(parts), list(recv_counts)
+
     def all_reduce_min(self, t):
         """In-place minimum of a small tensor over ranks."""
         if self.world > 1:
@@ -500,13 +551,21 @@ def _sor_normals_slabs(engine, coll, full, n_total, k_sor, std_mul, k_nrm, viewp
     result = dict(mean=mean, keep=keep, nx=nx, ny=ny, nz=nz, thr=math.nan, n_keep=0, stats=stats,
                   point=point, ownership="slabs", escalated=escalated, slab_axis=axis)
     if k_sor:
-        own = torch.tensor([nq], dtype=torch.int64, device="cpu" if coll.stage else engine.device)
-        all_counts = [int(c) for c in coll.all_gather_var(torch, own, [1] * world).tolist()]
-        assert sum(all_counts) == n_total, "the slabs do not partition the cloud"
-        points_all = coll.all_gather_var(torch, point, all_counts)
-        means_all = coll.all_gather_var(torch, mean, all_counts)
-        mean_full = buf("mean_by_index", n_total)
-        engine.scatter(means_all, points_all, mean_full)  # every index exactly once: no zeroing
+        # The threshold is a sequential sum over the means in index order.  Every mean first
+        # travels to the rank that owns its index range (all-to-all of (index, mean) pairs: 8 bytes
+        # a point, each pair over one link), is dropped into place there, and the ranges -- in rank
+        # order the whole vector in index order -- are all-gathered (4 bytes a point).
+        send_point, send_mean = buf("send_point", nq, "int32"), buf("send_mean", nq)
+        send_counts = engine.route_pairs(point, mean, n_total, world, send_point, send_mean)
+        recv_point, recv_counts = coll.all_to_all_var(torch, send_point, send_counts)
+        recv_mean, _ = coll.all_to_all_var(torch, send_mean, send_counts, recv_counts)
+        begin, end = shard_range(n_total, world, rank)
+        assert recv_point.numel() == end - begin, "the slabs do not partition the cloud"
+        mean_range = buf("mean_range", end - begin)
+        engine.scatter_range(recv_mean, recv_point, begin, mean_range)
+        range_counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0]
+                        for r in range(world)]
+        mean_full = coll.all_gather_var(torch, mean_range, range_counts)
         thr, ok, n_keep = engine.select(mean_full, std_mul, mean, keep)
         if ok:
             result["thr"] = thr

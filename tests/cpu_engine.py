@@ -136,6 +136,20 @@ class CpuEngine:
                 dst.copy_(torch.from_numpy(src[sel].copy()))
         return 0
 
+    def route_pairs(self, point, values, n_total, world, send_point, send_values):
+        from pointclouds_rs.dist import shard_range
+
+        p = point.numpy().view(np.uint32)
+        ends = np.array([shard_range(n_total, world, r)[1] for r in range(world)])
+        dest = np.searchsorted(ends, p, side="right")
+        order = np.argsort(dest, kind="stable")
+        send_point[: len(p)].copy_(torch.from_numpy(p[order].view(np.int32).copy()))
+        send_values[: len(p)].copy_(torch.from_numpy(values.numpy()[order].copy()))
+        return [int((dest == r).sum()) for r in range(world)]
+
+    def scatter_range(self, values, point, first, out):
+        out.numpy()[point.numpy().view(np.uint32).astype(np.int64) - first] = values.numpy()
+
     def scatter(self, values, point, out):
         out.numpy()[point.numpy().view(np.uint32)] = values.numpy()
 

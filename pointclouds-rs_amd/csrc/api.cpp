@@ -185,6 +185,9 @@ int finish_index(pcrs_index *ix, uint32_t k_hint, int algo) {
         algo == PCRS_ALGO_GRID || (algo == PCRS_ALGO_AUTO && ix->m >= kGridMinPoints);
     if (want_grid && ix->m > 0) {
         PCRS_TRY(pcrs_grid_build(ix, k_hint));  // leaves algo == BRUTE when a grid cannot help
+        // finer grids over crowded regions, for the searches of the cloud's own points (an index
+        // over a caller's box -- a rank's slab -- answers explicit queries and stays single)
+        if (ix->box.unbounded()) PCRS_TRY(pcrs_grid_refine(ix, k_hint));
     }
     return PCRS_OK;
 }

@@ -564,6 +564,10 @@ struct CellArgs {
     int n_radii;            // entries of wave_radii in use
     float useful_d2;        // 1-NN only: neighbours beyond this squared distance are of no use
                             // to the caller (+inf = no such bound)
+    uint32_t heavy_only;    // wave-per-query kernel: answer only the entries flagged PCRS_HEAVY_FLAG
+                            // and pass the others on to fail_list untouched (a finer level of a
+                            // refined index: what its cubes cannot certify is too sparse for its
+                            // cells and is better served by the next coarser level's lanes)
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
@@ -642,16 +646,16 @@ struct EveryRow {
     __device__ __forceinline__ bool operator()(uint32_t) const { return true; }
 };
 // row(points in the row) is asked before each row; false ends the walk there.
-template <class F4, class F1, class FR = EveryRow>
+template <int R = 1, class F4, class F1, class FR = EveryRow>
 __device__ __forceinline__ void walk_cube3(const CellArgs &a, int cx, int cy, int cz,
                                            const pcrs_q3 &q, F4 f4, F1 f1, FR row_ok = FR()) {
     const GridGeom &g = a.g;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
     const pcrs_p3 *base = reinterpret_cast<const pcrs_p3 *>(a.spts3);
-    for (int dz = -1; dz <= 1; ++dz) {
+    for (int dz = -R; dz <= R; ++dz) {
         const int zz = cz + dz;
         if (zz < 0 || zz >= g.nz) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
+        for (int dy = -R; dy <= R; ++dy) {
             const int yy = cy + dy;
             if (yy < 0 || yy >= g.ny) continue;
             const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
@@ -728,6 +732,15 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             qz = p.z;
         } else {
             qi = (a.qmode == 2) ? a.qlist[pos] : pos;
+            if (a.qmode == 2 && (qi & PCRS_HEAVY_FLAG) && a.heavy != 0xFFFFFFFFu) {
+                // a cube an earlier stage found too crowded for a lane: on to the wave kernel
+                if (a.fail_list) {
+                    const uint32_t f = atomicAdd(a.fail_count, 1u);
+                    a.fail_list[f] = qi;
+                    if (a.fail_bound) a.fail_bound[f] = __builtin_inff();
+                }
+                continue;
+            }
             qx = a.qx[qi];
             qy = a.qy[qi];
             qz = a.qz[qi];
@@ -765,11 +778,13 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
         // regions instead of walking them.
         uint32_t probe0 = 0, probe1 = 0;  // the slots the probe looked at (probe1 > probe0: answered by it)
         {
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            constexpr int RR = 1;  // cube half-width of this kernel
+            const int x0 = max(cx - RR, 0), x1 = min(cx + RR, g.nx - 1);
             uint32_t cube_pts = 0;
+            constexpr int SIDE = 2 * RR + 1;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int yy = cy + i % 3 - 1, zz = cz + i / 3 - 1;
+            for (int i = 0; i < SIDE * SIDE; ++i) {
+                const int yy = cy + i % SIDE - RR, zz = cz + i / SIDE - RR;
                 if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
                     const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
                     cube_pts += a.cell_start[row + x1 + 1] - a.cell_start[row + x0];
@@ -818,7 +833,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
                 });
 
         // ---- certification: every point outside the cube is farther than `margin`
-        const int R = a.R;
+        constexpr int R = 1;
         // (a list of zero distances is final: a point at distance zero lies where the query lies,
         // in the query's own cell)
         const float margin = cube_margin(g, cx, cy, cz, ux, uy, uz, R);
@@ -1387,6 +1402,10 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         const uint32_t entry = a.qlist[pos];
         const uint32_t qi = entry & ~PCRS_HEAVY_FLAG;
         const int first_radius = (entry & PCRS_HEAVY_FLAG) ? 0 : 1;
+        if (a.heavy_only && !(entry & PCRS_HEAVY_FLAG)) {
+            if (lane == 0 && a.fail_list) a.fail_list[atomicAdd(a.fail_count, 1u)] = qi;
+            continue;
+        }
         const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];  // finite: stage 1 filtered
         const float ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
         const int cx = cell_coord(qx, g.ox, g.inv, g.nx);
@@ -2129,6 +2148,49 @@ __global__ __launch_bounds__(GB_THREADS) void radius_cell_kernel(CellArgs a, flo
 }
 
 
+// Where a grid is crowded: the box (in cells) of the cells that hold more than `threshold` points,
+// as six maxima (the low sides stored as n - 1 - coordinate), their number and their points.
+struct DenseScan {
+    uint32_t hi[3], lo_rev[3];
+    uint32_t cells, pad;
+    unsigned long long points;
+};
+__global__ __launch_bounds__(GB_THREADS) void dense_scan_kernel(const uint32_t *cell_start,
+                                                                GridGeom g, uint32_t ncell,
+                                                                uint32_t threshold, DenseScan *out) {
+    __shared__ uint32_t smax[6];
+    __shared__ uint32_t scells;
+    __shared__ unsigned long long spoints;
+    if (threadIdx.x < 6) smax[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        scells = 0;
+        spoints = 0;
+    }
+    __syncthreads();
+    for (uint32_t c = blockIdx.x * GB_THREADS + threadIdx.x; c < ncell; c += gridDim.x * GB_THREADS) {
+        const uint32_t cnt = cell_start[c + 1] - cell_start[c];
+        if (cnt > threshold) {
+            const uint32_t cx = c % (uint32_t)g.nx, cy = (c / (uint32_t)g.nx) % (uint32_t)g.ny;
+            const uint32_t cz = c / ((uint32_t)g.nx * (uint32_t)g.ny);
+            atomicMax(&smax[0], cx);
+            atomicMax(&smax[1], cy);
+            atomicMax(&smax[2], cz);
+            atomicMax(&smax[3], (uint32_t)g.nx - 1u - cx);
+            atomicMax(&smax[4], (uint32_t)g.ny - 1u - cy);
+            atomicMax(&smax[5], (uint32_t)g.nz - 1u - cz);
+            atomicAdd(&scells, 1u);
+            atomicAdd(&spoints, (unsigned long long)cnt);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && scells) atomicMax(&out->hi[threadIdx.x], smax[threadIdx.x]);
+    if (threadIdx.x >= 3 && threadIdx.x < 6 && scells) atomicMax(&out->lo_rev[threadIdx.x - 3], smax[threadIdx.x]);
+    if (threadIdx.x == 0 && scells) {
+        atomicAdd(&out->cells, scells);
+        atomicAdd(&out->points, spoints);
+    }
+}
+
 // Puts the points of every cell into ascending original-index order (one thread per cell; the
 // scatter's atomics leave them in arrival order).  Used where a reproducible point order matters.
 __global__ __launch_bounds__(GB_THREADS) void sort_cells_kernel(const uint32_t *cell_start,
@@ -2222,6 +2284,28 @@ unsigned grid_for(pcrs_ctx *ctx, size_t n, int threads) {
     if (blocks == 0) blocks = 1;
     return (unsigned)blocks;
 }
+
+// Finer grids over crowded regions (pcrs_grid_refine); experiments may switch them off:
+// PCRS_GRID_LEVELS=0.
+static bool levels_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCRS_GRID_LEVELS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// how many times fuller than the average occupied cell the cell of the average point must be
+// for a grid to leave its crowded part to a finer level (experiments: PCRS_GRID_LEVEL_RATIO)
+static double level_ratio() {
+    static const double r = [] {
+        const char *e = getenv("PCRS_GRID_LEVEL_RATIO");
+        const double v = e ? atof(e) : 0.0;
+        return v >= 1.2 && v <= 100.0 ? v : 2.0;
+    }();
+    return r;
+}
+constexpr size_t kLevelMinPoints = 65536;  // smaller clouds: the launches of a level cost more than it saves
+constexpr int kLevelMaxDepth = 6;
 
 // Points per cell the grid aims for: the 27-cell cube then holds ~27 P candidates and the ball
 // of radius one cell ~4.2 P >= 2 K points, so the first stage certifies almost every query.
@@ -2460,6 +2544,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         return !(e && e[0] == '0');
     }();
     const bool dim_aware = dim_switch && k_hint >= 8 && !getenv("PCRS_GRID_OCC");
+    ix->aim = P;
     double P_surface = 0.75 * (double)k_hint;
     P_surface = P_surface < P ? P : (P_surface > 64.0 ? 64.0 : P_surface);
     double dim = hinted ? gh.dim : 3.0, prev_cell = 0.0, prev_occ = 0.0;
@@ -2523,7 +2608,20 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         if (attempt == 3 || fixed_cell) break;
         const uint32_t nonempty = *h_nonempty;
         double occ = (double)nvalid / (double)(nonempty ? nonempty : 1);
-        if (two_level && weighted_occupancy) {
+        unsigned long long squares_seen = 0;
+        if (two_level) memcpy(&squares_seen, h_nonempty + 2, sizeof(squares_seen));
+        // A cloud whose points mostly sit in cells many times fuller than the average occupied
+        // cell is not served by one cell size: this grid is then sized for its sparse part (the
+        // mean over the occupied cells) and the crowded part gets finer grids of its own
+        // (pcrs_grid_refine).
+        if (two_level) {  // what the accepted geometry looks like, for pcrs_grid_refine
+            ix->occ_mean = occ;
+            ix->occ_seen = (double)squares_seen / (double)nvalid - 1.0;
+        }
+        const bool leave_crowded_to_levels =
+            two_level && levels_enabled() && k_hint > 1 && nvalid >= kLevelMinPoints &&
+            (double)squares_seen / (double)nvalid - 1.0 > level_ratio() * occ;
+        if (two_level && weighted_occupancy && !leave_crowded_to_levels) {
             // What a search pays for is the occupancy a *point* sees, sum(c^2) / n (uniform
             // clouds: one more than the mean).  A scan that is dense near the sensor and sparse
             // far out has a modest mean over its occupied cells and hundreds of points in the
@@ -2563,6 +2661,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             prev_cell = cell;
             prev_occ = occ;
             const double aim = P + (3.0 - dim) * (P_surface - P);
+            ix->aim = aim;
             if (occ >= 0.75 * aim && occ <= 1.6 * aim) break;
             double f = pow(aim / occ, 1.0 / dim);
             f = f < 0.2 ? 0.2 : (f > 2.5 ? 2.5 : f);
@@ -2727,6 +2826,82 @@ int pcrs_slab_cuts(pcrs_ctx *ctx, const float *x, const float *y, const float *z
     return PCRS_OK;
 }
 
+int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth) {
+    pcrs_ctx *ctx = ix->ctx;
+    if (!levels_enabled() || ix->algo != PCRS_ALGO_GRID || k_hint <= 1 || depth >= kLevelMaxDepth ||
+        ix->nvalid < kLevelMinPoints || !(ix->aim > 0.0))
+        return PCRS_OK;
+    // Cells of much the same fullness (what a point sees is close to the mean over the occupied
+    // cells, as in any evenly sampled volume or surface) hold no crowded region worth a level: not
+    // even a look at the cells.  (Both figures are those of the accepted sort; a build that never
+    // read them back has none and is looked at.)
+    if (ix->occ_mean > 0.0 && ix->occ_seen < 2.0 * ix->occ_mean + 2.0) return PCRS_OK;
+    const GridGeom &g = ix->g;
+    const uint32_t threshold = (uint32_t)std::ceil(4.0 * ix->aim);
+    DevBuf d;
+    PCRS_HIP_CHECK(ctx, d.alloc(ctx, sizeof(DenseScan)));
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(d.p, 0, sizeof(DenseScan), ctx->stream));
+    hipLaunchKernelGGL(dense_scan_kernel, dim3(grid_for(ctx, ix->ncell, GB_THREADS)), dim3(GB_THREADS), 0,
+                       ctx->stream, ix->cell_start.as<uint32_t>(), g, ix->ncell, threshold,
+                       d.as<DenseScan>());
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(DenseScan) + 64, &pin));
+    PCRS_TRY(pcrs_launch_publish(ctx, d.p, pin, sizeof(DenseScan)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const DenseScan ds = *reinterpret_cast<const DenseScan *>(pin);
+    static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
+    const size_t enough = std::max<size_t>(16384, ix->nvalid / 20);
+    if (ds.cells == 0 || ds.points < enough) return PCRS_OK;
+    const int n[3] = {g.nx, g.ny, g.nz};
+    int lo_c[3], hi_c[3];
+    double vol = 1.0, whole = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        hi_c[a] = (int)ds.hi[a];
+        lo_c[a] = n[a] - 1 - (int)ds.lo_rev[a];
+        vol *= (double)(hi_c[a] - lo_c[a] + 1);
+        whole *= (double)n[a];
+    }
+    // crowded cells all over the grid: one box around them is the grid again
+    if (vol > 0.6 * whole) return PCRS_OK;
+    const double o[3] = {g.ox, g.oy, g.oz};
+    BoxFilter qbox = pcrs_no_box(), pbox = ix->box;
+    for (int a = 0; a < 3; ++a) {
+        // a side on the grid's own end has nothing of this grid behind it
+        if (lo_c[a] > 0) {
+            qbox.lo[a] = (float)(o[a] + (double)lo_c[a] * (double)g.cell);
+            pbox.lo[a] = (float)(o[a] + (double)(lo_c[a] - 1) * (double)g.cell);
+        }
+        if (hi_c[a] < n[a] - 1) {
+            qbox.hi[a] = (float)(o[a] + (double)(hi_c[a] + 1) * (double)g.cell);
+            pbox.hi[a] = (float)(o[a] + (double)(hi_c[a] + 2) * (double)g.cell);
+        }
+    }
+    pcrs_index *child = new (std::nothrow) pcrs_index();
+    if (!child) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    child->ctx = ctx;
+    child->x = ix->x;
+    child->y = ix->y;
+    child->z = ix->z;
+    child->m = ix->m;
+    child->k_hint = k_hint;
+    child->box = pbox;
+    int rc = pcrs_grid_build(child, k_hint);
+    if (debug)
+        fprintf(stderr, "pcrs grid level %d: %u crowded cells (> %u points) with %llu points in a box of "
+                        "%d x %d x %d cells; finer grid over %zu points, cell %.5g (this level %.5g)\n",
+                depth + 1, ds.cells, threshold, ds.points, hi_c[0] - lo_c[0] + 1, hi_c[1] - lo_c[1] + 1,
+                hi_c[2] - lo_c[2] + 1, child->nvalid, (double)child->g.cell, (double)g.cell);
+    // a level must be a real step: enough points, markedly smaller cells
+    if (rc != PCRS_OK || child->algo != PCRS_ALGO_GRID || child->nvalid < 16384 ||
+        !(child->g.cell < 0.8f * g.cell)) {
+        delete child;
+        return rc;
+    }
+    ix->child = child;
+    ix->child_qbox = qbox;
+    return pcrs_grid_refine(child, k_hint, depth + 1);
+}
+
 int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm) {
     pcrs_ctx *ctx = ix->ctx;
     if (ix->algo != PCRS_ALGO_GRID || ix->nvalid == 0)
@@ -2865,7 +3040,10 @@ int pcrs_launch_normals_from_cov(pcrs_ctx *ctx, size_t nq, const float *cov, con
     return PCRS_OK;
 }
 
-pcrs_index::~pcrs_index() { delete whole; }
+pcrs_index::~pcrs_index() {
+    delete whole;
+    delete child;
+}
 
 int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums,
                          uint32_t *total_out) {
@@ -2892,6 +3070,70 @@ int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums
 }
 
 // ----------------------------------------------------------------------------- host: query
+
+// identities of 2 to 24 neighbours: one walk with tagged keys (knn_tag_kernel)
+static bool lane_kernel_is_one_walk(int kb, bool collect) {
+    static const bool use_tag = [] {  // experiments only: PCRS_ONE_WALK=0
+        const char *e = getenv("PCRS_ONE_WALK");
+        return !(e && e[0] == '0');
+    }();
+    return use_tag && collect && kb >= 2 && kb <= 24;
+}
+
+static void launch_two_walk_kernel(pcrs_ctx *ctx, const CellArgs &a, const KnnOut &out, int kb,
+                                   unsigned blocks) {
+#define PCRS_CELL2_CALL(KK)                                                                    \
+    hipLaunchKernelGGL((knn_cell_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a, out)
+    PCRS_DISPATCH_K(kb, PCRS_CELL2_CALL)
+#undef PCRS_CELL2_CALL
+}
+
+// the lane-per-query kernel of a search for more than one neighbour
+static void launch_lane_kernel(pcrs_ctx *ctx, const CellArgs &a, const KnnOut &out, int kb,
+                               bool collect, unsigned blocks) {
+#define PCRS_CELL_CALL(KK)                                                                      \
+    do {                                                                                        \
+        if (collect)                                                                            \
+            hipLaunchKernelGGL((knn_cell_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0,  \
+                               ctx->stream, a, out);                                            \
+        else                                                                                    \
+            hipLaunchKernelGGL((knn_cell_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
+                               ctx->stream, a, out);                                            \
+    } while (0)
+    if (lane_kernel_is_one_walk(kb, collect)) {
+#define PCRS_TAG_CALL(KK)                                                                      \
+    hipLaunchKernelGGL((knn_tag_kernel<KK>), dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a, out)
+        switch (kb) {
+            case 2: PCRS_TAG_CALL(2); break;
+            case 4: PCRS_TAG_CALL(4); break;
+            case 8: PCRS_TAG_CALL(8); break;
+            case 12: PCRS_TAG_CALL(12); break;
+            case 16: PCRS_TAG_CALL(16); break;
+            case 17: PCRS_TAG_CALL(17); break;
+            case 21: PCRS_TAG_CALL(21); break;
+            default: PCRS_TAG_CALL(24); break;
+        }
+#undef PCRS_TAG_CALL
+        return;
+    }
+    PCRS_DISPATCH_K(kb, PCRS_CELL_CALL)
+#undef PCRS_CELL_CALL
+}
+
+static void launch_wave_kernel(pcrs_ctx *ctx, const CellArgs &a, const KnnOut &out, int kb, bool coll,
+                               unsigned blocks) {
+#define PCRS_WAVE_CALL(KK)                                                                      \
+    do {                                                                                        \
+        if (coll)                                                                               \
+            hipLaunchKernelGGL((knn_wave_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0,  \
+                               ctx->stream, a, out);                                            \
+        else                                                                                    \
+            hipLaunchKernelGGL((knn_wave_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
+                               ctx->stream, a, out);                                            \
+    } while (0)
+    PCRS_DISPATCH_K(kb, PCRS_WAVE_CALL)
+#undef PCRS_WAVE_CALL
+}
 
 // The sorted slots that `ch` picks, in slot order, into list (room for nvalid entries); their
 // number into *d_count (device).  Count per block of 1024 slots, scan, ordered write.
@@ -2950,6 +3192,177 @@ int pcrs_grid_gather_selected(pcrs_index *ix, float *ox, float *oy, float *oz, u
     return PCRS_OK;
 }
 
+// A search of the cloud's own points over an index with finer levels (pcrs_index::child).  Every
+// point is a query of the finest level whose query box holds it; the levels run finest first, each
+// with the stages of a single grid (lane-per-query kernel, two-walk kernel for what that hands
+// over, wave-per-query kernel for what neither certifies), and what a level cannot certify -- a
+// neighbourhood that reaches across an open face of its box -- joins the queries of the next
+// coarser one.  The outputs are indexed by point, so the levels simply fill the same arrays.
+static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &out_in,
+                             uint32_t kneed) {
+    pcrs_ctx *ctx = top->ctx;
+    KnnOut out = out_in;
+    const uint32_t m = (uint32_t)top->m;
+    std::vector<pcrs_index *> levels;
+    for (pcrs_index *l = top; l; l = l->child) levels.push_back(l);
+    const bool collect = out.idx || out.dist || out.count || out.nx;
+    const uint32_t keff = kneed;  // every level holds far more points than a register list
+    uint32_t kc = 0;
+    if (out.idx || out.dist || out.count) kc = out.k;
+    if (out.nx && out.k_nrm > kc) kc = out.k_nrm;
+    if (kc > keff) kc = keff;
+    const int kb = k_bucket(keff);
+    const bool one_walk = lane_kernel_is_one_walk(kb, collect);
+    DevBuf cov;
+    if (out.nx && !out.cov) {
+        PCRS_HIP_CHECK(ctx, cov.alloc(ctx, PCRS_REC_FLOATS * (size_t)m * sizeof(float)));
+        out.cov = cov.as<float>();
+    }
+    const bool timing_was = ctx->timing;
+    const uint32_t *esc_list = nullptr, *esc_count = nullptr;  // what the finer level left
+    for (int li = (int)levels.size() - 1; li >= 0; --li) {
+        pcrs_index *ix = levels[li];
+        const size_t list_elems = (size_t)m + 64;
+        const size_t need = (5 * list_elems + 64) * sizeof(uint32_t);
+        if (ix->fail_lists.bytes < need) PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
+        uint32_t *listA = ix->fail_lists.as<uint32_t>();
+        uint32_t *listB = listA + list_elems;
+        uint32_t *listC = listB + list_elems;
+        float *boundA = reinterpret_cast<float *>(listC + list_elems);
+        uint32_t *listS = listC + 2 * list_elems;  // the level's own queries (sorted slots)
+        if (!ix->counters.p) {
+            PCRS_HIP_CHECK(ctx, ix->counters.alloc(ctx, 32 * sizeof(uint32_t)));
+            PCRS_HIP_CHECK(ctx, hipMemsetAsync(ix->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
+            ix->counter_phase = 0;
+        }
+        uint32_t *counters = ix->counters.as<uint32_t>() + 16 * ix->counter_phase;
+        uint32_t *counters_next = ix->counters.as<uint32_t>() + 16 * (ix->counter_phase ^ 1);
+        if (!ix->spts3.p) {
+            PCRS_HIP_CHECK(ctx, ix->spts3.alloc(ctx, ix->nvalid * 3 * sizeof(float)));
+            hipLaunchKernelGGL(pack_xyz_kernel, dim3((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS)),
+                               dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(),
+                               (uint32_t)ix->nvalid, ix->spts3.as<float>());
+        }
+        // the level's own queries: inside its query box, outside the next finer level's
+        SlotChoice ch{};
+        ch.q_begin = 0;
+        ch.q_len = m;
+        ch.boxes = true;
+        ch.in = li > 0 ? levels[li - 1]->child_qbox : pcrs_no_box();
+        if (ix->child) {
+            ch.ex = ix->child_qbox;
+        } else {
+            for (int a3 = 0; a3 < 3; ++a3) ch.ex.lo[a3] = ch.ex.hi[a3] = 0.0f;  // excludes nothing
+        }
+        PCRS_TRY(choose_slots(ix, ch, listS, &counters[4]));
+
+        CellArgs a{};
+        a.g = ix->g;
+        a.cell_start = ix->cell_start.as<uint32_t>();
+        a.spts = ix->spts.as<float4>();
+        a.spts3 = ix->spts3.as<float>();
+        a.nvalid = (uint32_t)ix->nvalid;
+        a.rx = ix->x;
+        a.ry = ix->y;
+        a.rz = ix->z;
+        a.qx = ix->x;
+        a.qy = ix->y;
+        a.qz = ix->z;
+        a.nq = m;
+        a.q_begin = 0;
+        a.q_len = m;
+        a.kcert = keff;
+        a.kcollect = collect ? (kc ? kc : 1) : 0;
+        a.useful_d2 = __builtin_inff();
+        a.R = 1;
+        a.heavy = m >= PCRS_HEAVY_FLAG ? 0xFFFFFFFFu : 8192u;
+        a.wave_radii[0] = 1;
+        a.wave_radii[1] = 2;
+        a.wave_radii[2] = 4;
+        a.wave_radii[3] = 8;
+        a.wave_radii[4] = 1 << 20;
+        a.n_radii = 5;
+        a.skip = q.skip_flag;
+        a.zero_me = counters_next;
+        a.fail_list = listA;
+        a.fail_count = &counters[0];
+        a.fail_bound = boundA;
+        a.alt_list = listC;
+        a.alt_count = &counters[5];
+        // stage 1 over the level's own queries ...
+        a.qmode = 3;
+        a.qlist = listS;
+        a.qcount = &counters[4];
+        const unsigned lane_blocks = std::min((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS),
+                                              (unsigned)ctx->num_cus * 64u);
+        pcrs_timing_begin(ctx);
+        launch_lane_kernel(ctx, a, out, kb, collect, lane_blocks);
+        pcrs_timing_end(ctx);
+        ix->counter_phase ^= 1;
+        a.zero_me = nullptr;
+        ctx->timing = false;
+        // ... and over what the finer level could not certify
+        if (esc_list) {
+            a.qmode = 2;
+            a.qlist = esc_list;
+            a.qcount = esc_count;
+            launch_lane_kernel(ctx, a, out, kb, collect, (unsigned)ctx->num_cus * 4u);
+        }
+        a.alt_list = nullptr;
+        a.alt_count = nullptr;
+        if (one_walk) {
+            a.qmode = 2;
+            a.qlist = listC;
+            a.qcount = &counters[5];
+            launch_two_walk_kernel(ctx, a, out, kb, std::min(lane_blocks, (unsigned)ctx->num_cus * 8u));
+        }
+        // larger cubes, samples and balls for what is left, a wave per query
+        a.qmode = 2;
+        a.qlist = listA;
+        a.qcount = &counters[0];
+        a.qbound = boundA;
+        a.fail_list = listB;
+        a.fail_count = &counters[3];
+        a.fail_bound = nullptr;
+        static const bool pass_up = [] {  // experiments only: PCRS_GRID_PASS_UP=1
+            const char *e = getenv("PCRS_GRID_PASS_UP");
+            return e && e[0] == '1';
+        }();
+        a.heavy_only = (pass_up && li > 0) ? 1u : 0u;
+        launch_wave_kernel(ctx, a, out, kb, collect,
+                           (unsigned)std::min<size_t>(((size_t)m + 3) / 4, (size_t)ctx->num_cus * 8));
+        PCRS_HIP_CHECK(ctx, hipGetLastError());
+        ix->left_list = listB;
+        ix->left_count = &counters[3];
+        esc_list = listB;
+        esc_count = &counters[3];
+        ctx->timing = timing_was;
+        static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
+        if (debug) {
+            uint32_t c[8];
+            (void)hipMemcpyAsync(c, counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            fprintf(stderr, "pcrs search level %d (cell %.5g, %zu points): %u own queries, %u handed to the "
+                            "two-walk kernel, %u left by the lanes, %u passed on\n",
+                    li, (double)ix->g.cell, ix->nvalid, c[4], c[5], c[0], c[3]);
+        }
+    }
+    // what even the coarsest level (no open faces) could not certify: more ties than a wave lists
+    ctx->timing = false;
+    const int rc_bf = q.no_brute ? PCRS_OK
+                                 : pcrs_launch_knn_bf(ctx, top->x, top->y, top->z, top->m, q, out, kneed,
+                                                      esc_list, esc_count, m);
+    if (cov.p && rc_bf == PCRS_OK)
+        (void)pcrs_launch_normals_from_cov(ctx, m, cov.as<float>(), top->x, top->y, top->z, out);
+    ctx->timing = timing_was;
+    PCRS_TRY(rc_bf);
+    if (top->nvalid < top->m)
+        PCRS_TRY(pcrs_launch_invalid_defaults(ctx, top->x, top->y, top->z, q, out_in));
+    top->stats_dev = top->counters.as<uint32_t>() + 16 * (top->counter_phase ^ 1);
+    top->stats_nq = m;
+    return PCRS_OK;
+}
+
 int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in, uint32_t kneed) {
     pcrs_ctx *ctx = ix->ctx;
     KnnOut out = out_in;
@@ -2970,6 +3383,9 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     }
     const bool nn_only = out.nn_idx && !out.idx && !out.dist && !out.count && !out.mean && !out.nx;
     const uint32_t nq = (uint32_t)q.nq;
+    if (ix->child && q.self && q.out_offset == 0 && q.nq == ix->m && !nn_only && !q.only_list &&
+        !q.xform && keff == kneed)
+        return launch_knn_levels(ix, q, out_in, kneed);
     // A pending increment of the queries (KnnQuery::xform) is applied by the 1-NN kernel as it
     // loads them, when that kernel reads the caller's columns directly; otherwise here, first.
     const bool fuse_xform = q.xform && nn_only && !q.self && (q.coherent || nq < 32768u);
@@ -3037,52 +3453,15 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     a.kcollect = (collect || nn_only) ? (kc ? kc : 1) : 0;
     const int kb = k_bucket(keff);
 
-    bool one_walk = false;
-    auto launch_two_walk = [&](unsigned blocks) {
-#define PCRS_CELL2_CALL(KK)                                                                    \
-    hipLaunchKernelGGL((knn_cell_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a, out)
-        PCRS_DISPATCH_K(kb, PCRS_CELL2_CALL)
-#undef PCRS_CELL2_CALL
-    };
+    const bool one_walk = !nn_only && lane_kernel_is_one_walk(kb, collect);
+    auto launch_two_walk = [&](unsigned blocks) { launch_two_walk_kernel(ctx, a, out, kb, blocks); };
     auto launch = [&](unsigned blocks) {
         if (nn_only) {  // eight lanes per query
             hipLaunchKernelGGL(nn_cell_kernel, dim3(blocks * NN_SUB), dim3(GB_THREADS), 0,
                                ctx->stream, a, out);
             return;
         }
-#define PCRS_CELL_CALL(KK)                                                                      \
-    do {                                                                                        \
-        if (collect)                                                                            \
-            hipLaunchKernelGGL((knn_cell_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0,  \
-                               ctx->stream, a, out);                                            \
-        else                                                                                    \
-            hipLaunchKernelGGL((knn_cell_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
-                               ctx->stream, a, out);                                            \
-    } while (0)
-        // identities of 2 to 24 neighbours: one walk with tagged keys (knn_tag_kernel)
-        static const bool use_tag = [] {
-            const char *e = getenv("PCRS_ONE_WALK");
-            return !(e && e[0] == '0');
-        }();
-        one_walk = use_tag && collect && kb >= 2 && kb <= 24;
-        if (one_walk) {
-#define PCRS_TAG_CALL(KK)                                                                      \
-    hipLaunchKernelGGL((knn_tag_kernel<KK>), dim3(blocks), dim3(GB_THREADS), 0, ctx->stream, a, out)
-            switch (kb) {
-                case 2: PCRS_TAG_CALL(2); break;
-                case 4: PCRS_TAG_CALL(4); break;
-                case 8: PCRS_TAG_CALL(8); break;
-                case 12: PCRS_TAG_CALL(12); break;
-                case 16: PCRS_TAG_CALL(16); break;
-                case 17: PCRS_TAG_CALL(17); break;
-                case 21: PCRS_TAG_CALL(21); break;
-                default: PCRS_TAG_CALL(24); break;
-            }
-#undef PCRS_TAG_CALL
-            return;
-        }
-        PCRS_DISPATCH_K(kb, PCRS_CELL_CALL)
-#undef PCRS_CELL_CALL
+        launch_lane_kernel(ctx, a, out, kb, collect, blocks);
     };
 
     // stage 1: the 27-cell cube over every query
@@ -3205,18 +3584,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     // stages 2-4: larger cubes over the failures, one wave per query (their number is known only
     // on the device: fixed grid with a grid-stride loop)
     auto launch_wave = [&](unsigned blocks) {
-        const bool coll = collect || nn_only;
-#define PCRS_WAVE_CALL(KK)                                                                      \
-    do {                                                                                        \
-        if (coll)                                                                               \
-            hipLaunchKernelGGL((knn_wave_kernel<KK, true>), dim3(blocks), dim3(GB_THREADS), 0,  \
-                               ctx->stream, a, out);                                            \
-        else                                                                                    \
-            hipLaunchKernelGGL((knn_wave_kernel<KK, false>), dim3(blocks), dim3(GB_THREADS), 0, \
-                               ctx->stream, a, out);                                            \
-    } while (0)
-        PCRS_DISPATCH_K(kb, PCRS_WAVE_CALL)
-#undef PCRS_WAVE_CALL
+        launch_wave_kernel(ctx, a, out, kb, collect || nn_only, blocks);
     };
     if (!nn_only) {
         unsigned retry_blocks = (unsigned)std::min<size_t>((nq + 3) / 4, (size_t)ctx->num_cus * 8);

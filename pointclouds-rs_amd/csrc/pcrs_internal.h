@@ -200,6 +200,17 @@ struct pcrs_index {
     // valid until the next search on this index
     const uint32_t *left_list = nullptr;
     const uint32_t *left_count = nullptr;
+    // A finer grid over the box in which this grid's cells are crowded (a scan that is dense near
+    // the sensor, a blob in a sparse scene), itself refined where it is crowded in turn: a search
+    // of the cloud's own points answers every point at the finest level whose query box holds
+    // it.  child_qbox: the part of space whose points the child answers; the child indexes a
+    // margin of one of this grid's cells more.
+    pcrs_index *child = nullptr;
+    BoxFilter child_qbox = pcrs_no_box();
+    double aim = 0.0;  // points per occupied cell the build aimed at
+    // of the accepted sort, when it read them back: mean points per occupied cell, and the
+    // fullness of the cell the average point sits in (sum of squared counts / points - 1)
+    double occ_mean = 0.0, occ_seen = 0.0;
     // an index over the whole cloud, built on first need, for the queries an index over a box
     // cannot certify (their neighbourhood reaches across an open face)
     pcrs_index *whole = nullptr;
@@ -273,6 +284,8 @@ int pcrs_launch_knn_bf(pcrs_ctx *ctx, const float *rx, const float *ry, const fl
 // ---- grid (grid.hip)
 // cell_request > 0 fixes the cell edge (enlarged only if the cell budget demands it)
 int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request = 0.0f);
+// finer grids over the crowded part of a grid, level by level (see pcrs_index::child)
+int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth = 0);
 // radius count over the grid: possible when the ball fits a cube of at most 7^3 cells
 bool pcrs_grid_radius_ok(const pcrs_index *ix, float radius);
 int pcrs_launch_radius_count_grid(pcrs_index *ix, const KnnQuery &q, float radius,

@@ -154,7 +154,10 @@ def load_library():
         except Exception:
             pass
         lib = C.CDLL(LIB_PATH)
+        variant = bool(os.environ.get("PCRS_HIP_LIB"))
         for name, (res, args) in SIGNATURES.items():
+            if variant and not hasattr(lib, name):
+                continue  # an older build under comparison: it lacks the newer entry points
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

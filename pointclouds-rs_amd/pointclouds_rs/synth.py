@@ -91,3 +91,33 @@ def degenerate_cloud(n=300, seed=7):
     y[25] = np.inf
     z[33] = -np.inf
     return x, y, z
+
+
+def ring_scan(sweeps=1, seed=11, beams=64, azimuths=2048, height=1.73):
+    """A spinning-LiDAR shaped scan of a ground plane: `beams` rings of `azimuths` returns per
+    sweep around a sensor `height` above the ground, several sweeps of a moving sensor.  Dense
+    rings near the sensor, sparse ones far out: the density falls with the square of the range
+    (3.7 m to 99 m), by a factor of several hundred over the scan."""
+    rng = np.random.default_rng(seed)
+    elev = np.deg2rad(np.linspace(-24.8, -1.0, beams))  # below the horizon: ground hits
+    r = height / np.tan(-elev)
+    parts = []
+    for s in range(sweeps):
+        a = np.linspace(0, 2 * np.pi, azimuths, endpoint=False) + rng.uniform(0, 2 * np.pi / azimuths)
+        rr = (r[:, None] * (1 + rng.normal(0, 2e-3, (beams, azimuths)))).ravel()
+        aa = np.broadcast_to(a, (beams, azimuths)).ravel()
+        parts.append(np.stack([rr * np.cos(aa) + 0.8 * s, rr * np.sin(aa),
+                               rng.normal(0, 0.02, rr.size)], 1))
+    p = np.concatenate(parts).astype(F)
+    return tuple(np.ascontiguousarray(p[:, i]) for i in range(3))
+
+
+def blob_in_box(n_blob, n_background, seed=0, sigma=1e-3, centre=3.0, half=100.0):
+    """A tight Gaussian blob (a few millimetres across) inside a sparse uniform box 200 units wide,
+    shuffled: the whole blob falls into one cell of any grid sized for the box."""
+    rng = np.random.default_rng(seed)
+    c = (rng.normal(0, sigma, size=(n_blob, 3)) + centre).astype(F)
+    bg = rng.uniform(-half, half, size=(n_background, 3)).astype(F)
+    p = np.concatenate([c, bg])
+    p = p[rng.permutation(len(p))]
+    return tuple(np.ascontiguousarray(p[:, i]) for i in range(3))

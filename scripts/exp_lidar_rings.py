@@ -9,19 +9,10 @@ sys.path.insert(0, os.path.join(ROOT, "pointclouds-rs_amd"))
 import numpy as np
 from pointclouds_rs import hip
 
-rng = np.random.default_rng(11)
+from pointclouds_rs import synth
+
 for sweeps in ([int(a) for a in sys.argv[1:]] or [1, 8]):
-    beams, az = 64, 2048
-    elev = np.deg2rad(np.linspace(-24.8, -1.0, beams))      # below the horizon: ground hits
-    r = 1.73 / np.tan(-elev)                                # 3.7 m ... 99 m
-    parts = []
-    for s in range(sweeps):                                 # several sweeps of a moving sensor
-        a = np.linspace(0, 2 * np.pi, az, endpoint=False) + rng.uniform(0, 2 * np.pi / az)
-        rr = (r[:, None] * (1 + rng.normal(0, 2e-3, (beams, az)))).ravel()
-        aa = np.broadcast_to(a, (beams, az)).ravel()
-        parts.append(np.stack([rr * np.cos(aa) + 0.8 * s, rr * np.sin(aa), rng.normal(0, 0.02, rr.size)], 1))
-    p = np.concatenate(parts).astype(np.float32)
-    x, y, z = (np.ascontiguousarray(p[:, i]) for i in range(3))
+    x, y, z = synth.ring_scan(sweeps)
     ix = hip.Index(x, y, z, k_hint=17)
     for rep in range(3):
         t0 = time.perf_counter()

@@ -4,6 +4,8 @@ import numpy as np
 from pointclouds_rs import hip
 rng = np.random.default_rng(0)
 def run(name, x, y, z):
+    hip.sor(x, y, z, 16, 1.0)   # warm-up (the first call also loads the library)
+    hip.normals(x, y, z, 16)
     t0 = time.perf_counter()
     keep, nk, thr, mean = hip.sor(x, y, z, 16, 1.0)
     t1 = time.perf_counter()

@@ -1013,3 +1013,38 @@ def test_slab_indexes_partition_the_cloud_and_match_the_oracle(oracle, world):
         assert (seen == 1).all()
         if shrink < 1.0:
             assert escalated > 0  # the small halo does send queries to the whole-cloud index
+
+
+@pytest.mark.parametrize("cloud", ["rings", "blob"])
+def test_clouds_of_very_uneven_density_use_finer_levels_and_match_the_oracle(hip, oracle, cloud):
+    """A spinning-LiDAR shaped scan (density falling by a factor of hundreds from the sensor
+    outwards) and a millimetre blob in a box 200 units wide: the index gives the crowded part
+    finer grids of its own, every point is answered at the finest level that holds it, and what
+    a level cannot certify goes to the next coarser one.  Means, threshold, mask and lists must
+    be the oracle's; the normals within 1e-5."""
+    if cloud == "rings":
+        x, y, z = gen.ring_scan(1)          # 131 072 points
+        vp = (0.0, 0.0, 1.73)
+    else:
+        x, y, z = gen.blob_in_box(30_000, 50_000)
+        vp = (0.0, 0.0, 300.0)
+    k = 16
+    keep, n_keep, thr, mean = hip.sor(x, y, z, k, 1.0)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, k, 1.0, algo=1)
+    bad = np.flatnonzero(mean.view(np.uint32) != rmean.view(np.uint32))
+    assert len(bad) == 0, (len(bad), bad[:5], mean[bad[:5]], rmean[bad[:5]])
+    assert _bit_equal(thr, rthr) and n_keep == rn and np.array_equal(keep, rkeep)
+    keep2, nk2, thr2, nrm = hip.sor_normals(x, y, z, k, 1.0, k, vp)
+    ref = oracle.normals(x, y, z, k, vp, algo=1)
+    assert nk2 == rn and _bit_equal(thr2, rthr) and np.array_equal(keep2, rkeep)
+    assert normals_close(nrm, ref, 1e-5).mean() > 0.9999
+    got = hip.normals(x, y, z, 5, vp)
+    ref5 = oracle.normals(x, y, z, 5, vp, algo=1)
+    assert normals_close(got, ref5, 1e-5).mean() > 0.999
+    # explicit queries are answered by the coarsest grid alone (crowded cubes by the wave kernel)
+    ix = hip.Index(x, y, z, k_hint=k + 1)
+    q = np.random.default_rng(2).choice(len(x), 3000, replace=False)
+    idx, dist, cnt = ix.knn(x[q], y[q], z[q], k + 1)
+    ix.close()
+    ridx, rdist, _, rcnt = oracle.knn(x, y, z, x[q], y[q], z[q], k + 1, algo=1)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx) and _bit_equal(dist, rdist)

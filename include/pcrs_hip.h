@@ -199,6 +199,53 @@ int pcrs_ransac_plane_samples_dev(pcrs_ctx *ctx, const float *dx, const float *d
                                   float distance_threshold, float model[4], uint8_t *dinlier_mask,
                                   size_t *n_inliers, uint64_t *best_count);
 
+/* PointCloud::select / select_inverse by a mask, x / y / z columns on the device —
+ * crates/core/src/cloud.rs:103-162: the points whose mask byte is non-zero (zero with invert != 0)
+ * in their order, so that the stages of a pipeline hand device columns to each other.  dindex
+ * (nullable) receives their indices; the outputs need room for n points.  *n_out (nullable)
+ * receives their number; passing it makes the call wait for the stream. */
+int pcrs_select_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz, size_t n,
+                    const uint8_t *dmask, int invert, float *dox, float *doy, float *doz,
+                    uint32_t *dindex, size_t *n_out);
+
+/* The index triples ransac_plane_seeded would sample (ransac_plane.rs:75-79,141-165: three
+ * distinct indices below n, up to 100 redraws each, a triple is dropped when they fail) from a
+ * SplitMix64 stream seeded with `seed`, each draw (next * n) >> 64.  The reference draws from
+ * rand's StdRng, which cannot be reproduced without that crate: these are the triples of the
+ * Python mirror (pointclouds_rs.sample_triples), for callers that want that stream.  triples holds
+ * 3 * iterations indices; *n_triples receives how many triples were made.  Host code only. */
+int pcrs_sample_triples(size_t n, size_t iterations, uint64_t seed, uint32_t *triples,
+                        size_t *n_triples);
+
+/* The obstacle pipeline of the reference's example as one call —
+ * examples/python/kitti_obstacle_detection.py:87-124: voxel_downsample(voxel_size) ->
+ * statistical_outlier_removal(sor_k, sor_std_mul) -> ransac_plane_seeded(plane_threshold,
+ * plane_iterations, triples of pcrs_sample_triples(kept points, plane_iterations, plane_seed)) ->
+ * the points off the plane (select_inverse) -> euclidean_cluster(cluster_threshold, min, max).
+ * Every stage computes what its own entry point computes; the cloud is uploaded once and the
+ * intermediate clouds stay on the device.  Host buffers: obst_x/y/z (nullable, room for n) receive
+ * the obstacle cloud the clusters index into; cluster_offsets (n + 1) and cluster_indices (n) the
+ * clusters in CSR form as pcrs_euclidean_cluster gives them. */
+typedef struct pcrs_obstacle_params {
+    float voxel_size;
+    uint32_t sor_k;
+    float sor_std_mul;
+    float plane_threshold;
+    uint32_t plane_iterations;
+    uint64_t plane_seed;
+    float cluster_threshold;
+    size_t cluster_min_size, cluster_max_size;
+} pcrs_obstacle_params;
+typedef struct pcrs_obstacle_result {
+    size_t n_voxels, n_kept, n_ground, n_obstacles, n_clusters, n_cluster_points;
+    float plane[4];      /* nx, ny, nz, d */
+    float sor_threshold; /* NaN when none was computed */
+} pcrs_obstacle_result;
+int pcrs_obstacle_pipeline(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                           const pcrs_obstacle_params *params, pcrs_obstacle_result *result,
+                           float *obst_x, float *obst_y, float *obst_z, uint32_t *cluster_offsets,
+                           uint32_t *cluster_indices);
+
 /* ------------------------------------------- statistical_outlier_removal */
 
 /* The per-point loop of statistical_outlier_removal —

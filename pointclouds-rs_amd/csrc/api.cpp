@@ -194,6 +194,27 @@ int finish_index(pcrs_index *ix, uint32_t k_hint, int algo) {
 
 }  // namespace
 
+int pcrs_index_build_hinted_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                                size_t m, uint32_t k_hint, pcrs_index **out) {
+    *out = nullptr;
+    pcrs_index *ix = new (std::nothrow) pcrs_index();
+    if (!ix) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    ix->ctx = ctx;
+    ix->x = dx;
+    ix->y = dy;
+    ix->z = dz;
+    ix->m = m;
+    ix->k_hint = k_hint;
+    ix->use_hint = true;
+    const int rc = finish_index(ix, k_hint, PCRS_ALGO_AUTO);
+    if (rc != PCRS_OK) {
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return PCRS_OK;
+}
+
 // ------------------------------------------------------------------------------------ context
 
 extern "C" {
@@ -1179,6 +1200,30 @@ int pcrs_scatter_f32_dev(pcrs_ctx *ctx, const float *dvalues, const uint32_t *dp
     if (n && (!dvalues || !dpoint || !dout))
         return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
     return pcrs_launch_scatter_perm(ctx, dvalues, dpoint, n, dout);
+} catch (...) {
+    return pcrs_on_exception(ctx);
+}
+
+int pcrs_select_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz, size_t n,
+                    const uint8_t *dmask, int invert, float *dox, float *doy, float *doz,
+                    uint32_t *dindex, size_t *n_out) try {
+    PCRS_TRY(bind_device(ctx));
+    if (n_out) *n_out = 0;
+    if (n == 0) return PCRS_OK;
+    if (!dx || !dy || !dz || !dmask || !dox || !doy || !doz)
+        return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "null pointer");
+    DevBuf total;
+    PCRS_HIP_CHECK(ctx, total.alloc(ctx, sizeof(uint32_t)));
+    PCRS_TRY(pcrs_launch_select(ctx, dx, dy, dz, n, dmask, invert, dox, doy, doz, dindex,
+                                total.as<uint32_t>()));
+    if (n_out) {
+        void *pin = nullptr;
+        PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &pin));
+        PCRS_TRY(pcrs_launch_publish(ctx, total.p, pin, sizeof(uint32_t)));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        *n_out = *reinterpret_cast<uint32_t *>(pin);
+    }
+    return PCRS_OK;
 } catch (...) {
     return pcrs_on_exception(ctx);
 }

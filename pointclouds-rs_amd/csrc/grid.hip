@@ -2448,7 +2448,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     const unsigned nb = grid_for(ctx, m, GB_THREADS);
     // (the blocks write their partial boxes straight into pinned host memory: no copy command)
     void *pin = nullptr;
-    PCRS_TRY(pcrs_ctx_pinned(ctx, nb * sizeof(BBoxPartial) + 64, &pin));
+    PCRS_TRY(pcrs_ctx_pinned(ctx, std::max<size_t>(nb * sizeof(BBoxPartial), 512) + 64, &pin));
     BBoxPartial *hp = reinterpret_cast<BBoxPartial *>(pin);
     const BoxFilter box = ix->box;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -2515,7 +2515,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     // (Only for clouds that arrive in host memory: the ranks of a sharded run build their indices
     // over device columns and must all derive the same geometry from the cloud alone, whatever
     // each of them has built before.)
-    if (use_hint && ix->own_x.p && !fixed_cell && gh.cell > 0.0 && gh.k_hint == k_hint &&
+    if (use_hint && (ix->own_x.p || ix->use_hint) && !fixed_cell && gh.cell > 0.0 && gh.k_hint == k_hint &&
         (double)nvalid > 0.7 * (double)gh.n && (double)nvalid < 1.3 * (double)gh.n &&
         emax > 0.7 * gh.emax && emax < 1.3 * gh.emax) {
         cell = gh.cell * pow((double)gh.n / (double)nvalid, 1.0 / gh.dim);

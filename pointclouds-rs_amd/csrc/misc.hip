@@ -379,6 +379,57 @@ __global__ __launch_bounds__(256) void scatter_offset_kernel(const float *in, co
     if (i < n) out[point[i] - first] = in[i];
 }
 
+// PointCloud::select by a mask (crates/core/src/cloud.rs:103-140 for x, y, z): the points whose
+// mask byte is non-zero (or zero, with invert), in their order.  Count per block of 1024, scan,
+// ordered write: no atomics, the order is the input's.
+constexpr int SEL_PER_THREAD = 4;
+constexpr int SEL_BLOCK = 256 * SEL_PER_THREAD;
+__device__ __forceinline__ uint32_t select_flags(const uint8_t *mask, size_t n, size_t first, int invert) {
+    uint32_t f = 0;
+#pragma unroll
+    for (int i = 0; i < SEL_PER_THREAD; ++i)
+        if (first + i < n && ((mask[first + i] != 0) != (invert != 0))) f |= 1u << i;
+    return f;
+}
+__global__ __launch_bounds__(256) void select_count_kernel(const uint8_t *mask, size_t n, int invert,
+                                                           uint32_t *block_count) {
+    __shared__ uint32_t wsum[4];
+    const size_t first = (size_t)blockIdx.x * SEL_BLOCK + threadIdx.x * SEL_PER_THREAD;
+    uint32_t c = __popc(select_flags(mask, n, first, invert));
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void select_write_kernel(const float *x, const float *y, const float *z,
+                                                           const uint8_t *mask, size_t n, int invert,
+                                                           const uint32_t *block_offset, float *ox,
+                                                           float *oy, float *oz, uint32_t *oidx) {
+    __shared__ uint32_t wsum[4];
+    const size_t first = (size_t)blockIdx.x * SEL_BLOCK + threadIdx.x * SEL_PER_THREAD;
+    const uint32_t f = select_flags(mask, n, first, invert);
+    const uint32_t c = __popc(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t at = block_offset[blockIdx.x] + incl - c;
+    for (int w = 0; w < wave; ++w) at += wsum[w];
+#pragma unroll
+    for (int i = 0; i < SEL_PER_THREAD; ++i)
+        if (f & (1u << i)) {
+            ox[at] = x[first + i];
+            oy[at] = y[first + i];
+            oz[at] = z[first + i];
+            if (oidx) oidx[at] = (uint32_t)(first + i);
+            ++at;
+        }
+}
+
 // A few words from device memory straight into pinned host memory: a kernel of one wave costs
 // less than a copy command, and the host then only waits for the stream.
 __global__ void publish_words_kernel(const uint32_t *src, uint32_t *host_dst, uint32_t nwords) {
@@ -401,6 +452,32 @@ int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *per
     if (n == 0) return PCRS_OK;
     hipLaunchKernelGGL(scatter_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        ctx->stream, in, perm, n, out);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+// d_total (nullable, device): receives the number of points selected
+int pcrs_launch_select(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                       const uint8_t *mask, int invert, float *ox, float *oy, float *oz,
+                       uint32_t *oidx, uint32_t *d_total) {
+    if (n >= 0xFFFFFFFFull) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "clouds are limited to 2^32-2 points");
+    DevBuf counts, sums, total;
+    const uint32_t blocks = (uint32_t)((n + SEL_BLOCK - 1) / SEL_BLOCK);
+    PCRS_HIP_CHECK(ctx, counts.alloc(ctx, ((size_t)blocks + 8) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, sums.alloc(ctx, ((size_t)blocks / 1024 + 4) * sizeof(uint32_t)));
+    if (!d_total) {
+        PCRS_HIP_CHECK(ctx, total.alloc(ctx, sizeof(uint32_t)));
+        d_total = total.as<uint32_t>();
+    }
+    if (n == 0) {
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
+        return PCRS_OK;
+    }
+    hipLaunchKernelGGL(select_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mask, n, invert,
+                       counts.as<uint32_t>());
+    PCRS_TRY(pcrs_launch_scan_u32(ctx, counts.as<uint32_t>(), blocks, sums.as<uint32_t>(), d_total));
+    hipLaunchKernelGGL(select_write_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x, y, z, mask, n,
+                       invert, counts.as<uint32_t>(), ox, oy, oz, oidx);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

@@ -177,6 +177,7 @@ struct pcrs_index {
     BoxFilter box = pcrs_no_box();
     // bounds that hold every point the grid takes and an upper limit of their number, from a
     // caller that has just measured the cloud: the build then skips its own pass for them
+    bool use_hint = false;  // start from the context's last geometry although the columns are device memory
     bool have_bounds = false;
     double bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
     size_t bounds_n_upper = 0;
@@ -381,6 +382,12 @@ int pcrs_launch_mask(pcrs_ctx *ctx, const float *mean, size_t n, float thr, uint
 int pcrs_launch_publish(pcrs_ctx *ctx, const void *d_src, void *pinned_dst, size_t bytes);
 int pcrs_launch_scatter_perm(pcrs_ctx *ctx, const float *in, const uint32_t *perm, size_t n,
                              float *out);
+// PointCloud::select by a mask (cloud.rs:103-140), x / y / z only: the points whose mask byte is
+// non-zero (zero with invert) in input order; oidx (nullable) their indices, d_total (nullable,
+// device) their number.  The outputs need room for n points.
+int pcrs_launch_select(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
+                       const uint8_t *mask, int invert, float *ox, float *oy, float *oz,
+                       uint32_t *oidx, uint32_t *d_total);
 // out[point[i] - first] = in[i]
 int pcrs_launch_scatter_offset(pcrs_ctx *ctx, const float *in, const uint32_t *point, size_t n,
                                uint32_t first, float *out);
@@ -470,6 +477,12 @@ int pcrs_static_scratch(pcrs_ctx *ctx, void **ptr, size_t *bytes);
 // {thr, has_finite, n_keep} from the device scalars and the mask count into *d_result
 int pcrs_launch_select_result(pcrs_ctx *ctx, const void *d_scalars,
                               const unsigned long long *d_count, pcrs_sor_select_result *d_result);
+
+// pcrs_index_build_dev for a caller that feeds one cloud after another of the same kind from
+// device memory (the frames of a sensor): the build starts from the geometry the context's last
+// build ended with (api.cpp)
+int pcrs_index_build_hinted_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
+                                size_t m, uint32_t k_hint, pcrs_index **out);
 
 // ---- host math (host_math.cpp)
 void pcrs_host_compose(const float ra[9], const float ta[3], const float rb[9], const float tb[3],

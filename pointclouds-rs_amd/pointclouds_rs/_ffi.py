@@ -44,6 +44,20 @@ class IcpResultC(C.Structure):
     ]
 
 
+class ObstacleParamsC(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("sor_k", C.c_uint32), ("sor_std_mul", C.c_float),
+                ("plane_threshold", C.c_float), ("plane_iterations", C.c_uint32),
+                ("plane_seed", C.c_uint64), ("cluster_threshold", C.c_float),
+                ("cluster_min_size", C.c_size_t), ("cluster_max_size", C.c_size_t)]
+
+
+class ObstacleResultC(C.Structure):
+    _fields_ = [("n_voxels", C.c_size_t), ("n_kept", C.c_size_t), ("n_ground", C.c_size_t),
+                ("n_obstacles", C.c_size_t), ("n_clusters", C.c_size_t),
+                ("n_cluster_points", C.c_size_t), ("plane", C.c_float * 4),
+                ("sor_threshold", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/pcrs_hip.h declares
 _V = C.c_void_p
 _F3 = [_V, _V, _V]  # three column pointers (host or device)
@@ -91,6 +105,10 @@ SIGNATURES = {
     "pcrs_sor_normals_slots_dev": (C.c_int, [_V, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32,
                                              c_float_p, _V, _V, _V, _V, _V]),
     "pcrs_scatter_f32_dev": (C.c_int, [_V, _V, _V, C.c_size_t, _V]),
+    "pcrs_select_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, _V, C.c_int, _V, _V, _V, _V, c_size_p]),
+    "pcrs_sample_triples": (C.c_int, [C.c_size_t, C.c_size_t, C.c_uint64, _V, c_size_p]),
+    "pcrs_obstacle_pipeline": (C.c_int, [_V] + _F3 + [C.c_size_t, C.POINTER(ObstacleParamsC),
+                                                      C.POINTER(ObstacleResultC), _V, _V, _V, _V, _V]),
     "pcrs_route_pairs_dev": (C.c_int, [_V, _V, _V, C.c_size_t, C.c_size_t, C.c_uint32, _V, _V, c_size_p]),
     "pcrs_scatter_range_f32_dev": (C.c_int, [_V, _V, _V, C.c_size_t, C.c_size_t, _V]),
     "pcrs_slab_cuts_dev": (C.c_int, [_V] + _F3 + [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_int),

@@ -216,6 +216,46 @@ def euclidean_cluster(x, y, z, distance_threshold, min_size, max_size, device=0)
     return [indices[offsets[c]:offsets[c + 1]].copy() for c in range(nc.value)]
 
 
+def sample_triples(n, iterations, seed):
+    """pcrs_sample_triples: the (S, 3) index triples of the mirror's SplitMix64 stream."""
+    lib = _ffi.load_library()
+    out = np.zeros((max(int(iterations), 1), 3), dtype=np.uint32)
+    ns = C.c_size_t(0)
+    rc = lib.pcrs_sample_triples(int(n), int(iterations), int(seed) & ((1 << 64) - 1), _ptr(out),
+                                 C.byref(ns))
+    if rc != 0:
+        raise _ffi.PcrsError(rc, "pcrs_sample_triples")
+    return out[: ns.value].copy()
+
+
+def obstacle_pipeline(x, y, z, voxel_size=0.15, sor_k=20, sor_std_mul=2.0, plane_threshold=0.15,
+                      plane_iterations=500, plane_seed=1234, cluster_threshold=0.8, cluster_min_size=10,
+                      cluster_max_size=20000, want_obstacles=True, device=0):
+    """voxel_downsample -> statistical_outlier_removal -> ransac_plane -> drop the plane ->
+    euclidean_cluster in one call (pcrs_obstacle_pipeline).  Returns a dict: the stage counts,
+    the plane (normal, d), the SOR threshold, the obstacle cloud (x, y, z) and the clusters as a
+    list of index arrays into it, largest first."""
+    ctx = get_context(device)
+    x, y, z = _col(x), _col(y), _col(z)
+    n = len(x)
+    prm = _ffi.ObstacleParamsC(float(voxel_size), int(sor_k), float(sor_std_mul), float(plane_threshold),
+                               int(plane_iterations), int(plane_seed) & ((1 << 64) - 1),
+                               float(cluster_threshold), int(cluster_min_size), int(cluster_max_size))
+    res = _ffi.ObstacleResultC()
+    obst = [np.empty(max(n, 1), dtype=np.float32) for _ in range(3)] if want_obstacles else [None] * 3
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    indices = np.zeros(max(n, 1), dtype=np.uint32)
+    ctx.check(ctx.lib.pcrs_obstacle_pipeline(ctx.handle, _ptr(x), _ptr(y), _ptr(z), n, C.byref(prm),
+                                             C.byref(res), *[_ptr(o) for o in obst], _ptr(offsets),
+                                             _ptr(indices)))
+    no = int(res.n_obstacles)
+    return dict(n_voxels=int(res.n_voxels), n_kept=int(res.n_kept), n_ground=int(res.n_ground),
+                n_obstacles=no, plane_normal=np.array(res.plane[:3], dtype=np.float32),
+                plane_d=float(res.plane[3]), sor_threshold=float(res.sor_threshold),
+                obstacles=tuple(o[:no] for o in obst) if want_obstacles else None,
+                clusters=[indices[offsets[c]:offsets[c + 1]] for c in range(int(res.n_clusters))])
+
+
 def normals(x, y, z, k, viewpoint=(0.0, 0.0, 0.0), device=0):
     """estimate_normals_with_viewpoint on columns: (nx, ny, nz); empty when k == 0."""
     ctx = get_context(device)

@@ -347,6 +347,68 @@ def test_obstacle_pipeline_matches_oracle(hip, oracle):
         assert np.array_equal(a, b)
 
 
+def test_obstacle_pipeline_in_one_call_matches_the_stages(hip, oracle):
+    """pcrs_obstacle_pipeline (one upload, intermediate clouds on the device) against the same
+    stages run one by one on the oracle: counts, threshold, plane, obstacle cloud and clusters."""
+    import pointclouds_rs as pc
+
+    for seed, sizes in ((43, (40000, 2500, 800)), (7, (9000, 500, 100))):
+        x, y, z = gen.kitti_scene(seed, *sizes)
+        out = hip.obstacle_pipeline(x, y, z, 0.15, 20, 2.0, 0.15, 500, 1234, 0.8, 10, 20000)
+        g = oracle.voxel_downsample(x, y, z, 0.15)
+        rkeep, rn, rthr, _ = oracle.sor(*g, 20, 2.0, algo=1)
+        c = [col[rkeep] for col in g]
+        smp = pc.sample_triples(len(c[0]), 500, 1234)
+        rnrm, rd, rinl, rbest = oracle.ransac_plane_samples(*c, smp, 0.15)
+        mask = np.ones(len(c[0]), dtype=bool)
+        mask[rinl] = False
+        obst = [col[mask] for col in c]
+        rcl = oracle.euclidean_cluster(*obst, 0.8, 10, 20000)
+        assert out["n_voxels"] == len(g[0]) and out["n_kept"] == rn and out["n_ground"] == len(rinl)
+        assert _bit_equal(out["sor_threshold"], rthr)
+        assert _bit_equal(out["plane_normal"], rnrm) and out["plane_d"] == rd
+        assert out["n_obstacles"] == len(obst[0])
+        for a, b in zip(out["obstacles"], obst):
+            assert _bit_equal(a, b)
+        assert len(out["clusters"]) == len(rcl) >= 1
+        for a, b in zip(out["clusters"], rcl):
+            assert np.array_equal(a, b)
+    # degenerate frames: nothing, one point, k = 0 (statistical_outlier.rs:5-12)
+    e = np.empty(0, dtype=F)
+    out = hip.obstacle_pipeline(e, e, e)
+    assert out["n_voxels"] == 0 and out["clusters"] == []
+    out = hip.obstacle_pipeline([1.0], [2.0], [3.0], cluster_min_size=1)
+    assert out["n_voxels"] == 1 and out["n_kept"] == 1 and out["n_ground"] == 0 and out["n_obstacles"] == 1
+    assert [list(c) for c in out["clusters"]] == [[0]]
+    x, y, z = gen.kitti_scene(7, 3000, 100, 50)
+    out = hip.obstacle_pipeline(x, y, z, sor_k=0)
+    assert out["n_voxels"] > 0 and out["n_kept"] == 0 and out["clusters"] == []
+
+
+def test_select_dev_is_pointcloud_select(hip):
+    from pointclouds_rs.dist import HipEngine
+    import ctypes as C
+
+    eng = HipEngine.shared(0)
+    rng = np.random.default_rng(4)
+    n = 100_003
+    cols = [rng.normal(size=n).astype(F) for _ in range(3)]
+    mask = (rng.random(n) < 0.37).astype(np.uint8)
+    d = [eng.from_numpy(c) for c in cols]
+    dm = eng.from_numpy(mask)
+    for invert in (0, 1):
+        o = [eng.empty(n) for _ in range(3)]
+        oi = eng.empty(n, "int32")
+        cnt = C.c_size_t()
+        eng.ctx.check(eng.lib.pcrs_select_dev(eng.ctx.handle, *[eng._p(c) for c in d], n, eng._p(dm), invert,
+                                              *[eng._p(c) for c in o], eng._p(oi), C.byref(cnt)))
+        want = np.flatnonzero((mask != 0) != bool(invert))
+        assert cnt.value == len(want)
+        assert np.array_equal(oi.cpu().numpy()[: len(want)].view(np.uint32), want.astype(np.uint32))
+        for got, c in zip(o, cols):
+            assert np.array_equal(got.cpu().numpy()[: len(want)], c[want])
+
+
 def test_knn_strays_over_dense_surface(hip, oracle):
     """Stray points high above (and far beside) a dense plane: their neighbours lie many cells
     away, in a small patch of the plane.  The retry stage bounds their K-th distance from a sample

@@ -100,3 +100,17 @@ def test_sample_triples_vectorised_road_equals_the_definition():
         a = pc.sample_triples(n, it, seed)
         b = pc._sample_triples_scalar(n, it, seed) if n >= 3 else np.zeros((0, 3), np.uint32)
         assert a.dtype == np.uint32 and a.shape == b.shape and np.array_equal(a, b), (n, it, seed)
+
+
+def test_sample_triples_of_the_library_are_the_mirrors():
+    """pcrs_sample_triples (host code of the library, used inside pcrs_obstacle_pipeline) against
+    the Python definition, draw for draw, redraws and dropped triples included."""
+    import pointclouds_rs as pc
+    from pointclouds_rs import hip
+
+    for n, it, seed in ((1000, 500, 1234), (5, 60, 7), (3, 40, 99), (44000, 500, 2 ** 63 + 5), (2, 10, 1),
+                        (4, 200, 0)):
+        a = pc._sample_triples_scalar(n, it, seed)
+        b = hip.sample_triples(n, it, seed)
+        assert np.array_equal(a, b), (n, it, seed)
+        assert np.array_equal(pc.sample_triples(n, it, seed), a)

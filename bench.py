@@ -213,7 +213,20 @@ def run_sor_normals(args):
     if world > 1:
         outputs.update(point=engine.empty(cap, "int32"), mean_by_index=engine.empty(n_total))
 
+    # --dist-driver native: the library's own driver (pcrs_dist_sor_normals_dev, collectives issued
+    # on RCCL inside the call) over a communicator of its own; the id travels over torch's.
+    native = args.dist_driver == "native" and world > 1 and not rehearse
+    comm = None
+    if native:
+        blob = [engine.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(blob, src=0)
+        comm = engine.dist_comm_init(blob[0], rank, world)
+        native_out = {k: outputs[k] for k in ("point", "mean", "keep", "nx", "ny", "nz")}
+
     def step(want_stats=False):
+        if native and not want_stats:
+            return engine.dist_sor_normals(comm, rank, world, shard, n_total, K_SOR, STD_MUL, K_NRM,
+                                           vp, outputs=native_out)
         return sor_normals_sharded(engine, coll, shard, n_total, K_SOR, STD_MUL, K_NRM, vp, outputs,
                                    want_stats=want_stats, ownership=ownership)
 
@@ -276,6 +289,7 @@ def run_sor_normals(args):
                 "name": args.config,
                 "points_per_gpu": n_total // world,
                 "ownership": res["ownership"],
+                "driver": "libpcrs_hip (pcrs_dist_sor_normals_dev)" if native else "pointclouds_rs.dist",
                 "queries_rank0": nq,
                 "n_keep_rank0": int(res["n_keep"]),
                 "threshold": res["thr"],
@@ -314,6 +328,8 @@ def run_sor_normals(args):
         if world == 1 and not c4 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(*full_host, synth)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        engine.dist_comm_destroy(comm)
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -695,6 +711,9 @@ def main():
     ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2")
     ap.add_argument("--points", type=int, default=0,
                     help="points per GPU (c2), points in all (c4), points per scan (c3); 0 = the config's own size")
+    ap.add_argument("--dist-driver", choices=("python", "native"), default="python",
+                    help="several GPUs: pointclouds_rs.dist over torch.distributed, or the library's "
+                         "own driver over a communicator of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true",
                     help="skip the side timings of the stages around the hot path")

@@ -525,6 +525,71 @@ int pcrs_icp_register(pcrs_ctx *ctx, int mode, const float *sx, const float *sy,
              const float *tny, const float *tnz, size_t n_normals, uint32_t max_iterations,
              float tolerance, float max_correspondence_distance, pcrs_icp_result *out);
 
+/* ---------------------------------------------------- several GPUs, from C */
+
+/* One cloud over the GPUs of a node with the collectives issued by the library itself on RCCL
+ * (no counterpart in the reference, which is a single-process CPU library): the two sharded
+ * drivers of pointclouds_rs/dist.py -- sor_normals_sharded(ownership="slabs") with its fallback
+ * to index ranges (dist.py:426-573) and icp_sharded (dist.py:576-641) -- as one call per rank,
+ * for hosts without Python.  One process (or thread) per GPU, each with its own context; every
+ * rank makes the same call with the same arguments apart from its shard.  RCCL is loaded when
+ * the first of these entry points runs (librccl.so.1, the copy already in the process if there is
+ * one), so the library itself loads on a machine without it; they fail with PCRS_ERR_HIP when it
+ * cannot be found.
+ *
+ * `nccl_comm` is an ncclComm_t over the participating ranks: one the host already has, or one
+ * from pcrs_dist_comm_init -- rank 0 fills id[PCRS_DIST_UNIQUE_ID_BYTES] with
+ * pcrs_dist_unique_id and hands the bytes to the other ranks by whatever means the host has (a
+ * file, a socket, MPI), then every rank calls pcrs_dist_comm_init with its rank.  The collectives
+ * run on the context's stream.
+ *
+ * The cloud is sharded in index order: rank r holds the contiguous range of n_total points that
+ * starts at r * (n_total / world) + min(r, n_total % world), the first n_total % world ranges
+ * one point longer (shard_range, dist.py:36-40).
+ *
+ * pcrs_dist_sor_normals_dev   dx/dy/dz: this rank's n_local points (device).  All ranks gather
+ *   the columns, every rank indexes its own slab of space plus a halo and answers the slab's
+ *   points (pcrs_slab_index_build_dev, pcrs_sor_normals_selected_dev), the means are routed to
+ *   the owners of their index ranges and gathered in index order, and every rank derives the
+ *   same threshold from them (statistical_outlier.rs:43-62) and writes the mask of the points it
+ *   answered.  Outputs (device, room for `capacity` points each; a slab holds about
+ *   n_total / world points, at most n_total): dpoint[i] = index in the whole cloud of the i-th
+ *   answered point, dmean / dkeep / dnx / dny / dnz[i] its results -- bit for bit what
+ *   pcrs_sor_normals writes at that index on one GPU.  dnx/dny/dnz may be NULL (no normals);
+ *   k_sor == 0 skips the outlier test (dmean, dkeep may then be NULL).  The points answered by
+ *   all ranks partition the cloud.  When the cloud has no slabs (non-finite points, no extent,
+ *   too few points) every rank answers its own index range from an index over the whole cloud
+ *   and result->by_slabs is 0.  Fails with PCRS_ERR_INVALID_ARG when `capacity` is smaller than
+ *   the number of points this rank has to answer.
+ * pcrs_dist_icp_run   the loop of icp.rs:125-206 / icp_plane.rs:20-97 with the source split over
+ *   the ranks: `icp` holds this rank's shard of the source (its length must be the rank's index
+ *   range of n_source_total) and the whole target.  Per iteration the ranks all-gather their
+ *   PCRS_ICP_NSUMS partial sums (and, for tolerance > 0, dist*dist of their points, so that the
+ *   loop is steered by the reference's own f32 rmse); every rank ends with the same result, equal
+ *   to pcrs_icp_run's on one GPU over the whole source up to the order of the f64 partial sums. */
+#define PCRS_DIST_UNIQUE_ID_BYTES 128
+typedef struct pcrs_dist_sor_result {
+    size_t n_answered;  /* points this rank answered (entries of the outputs) */
+    size_t n_keep;      /* kept among them */
+    size_t n_escalated; /* answered from the whole-cloud index instead of the slab's */
+    float threshold;    /* the same on every rank; NaN when no mean is finite */
+    int has_finite;
+    int by_slabs;       /* 1: ownership by slabs of space, 0: by index ranges */
+} pcrs_dist_sor_result;
+int pcrs_dist_unique_id(char id[PCRS_DIST_UNIQUE_ID_BYTES]);
+int pcrs_dist_comm_init(pcrs_ctx *ctx, const char id[PCRS_DIST_UNIQUE_ID_BYTES], int rank, int world,
+                        void **nccl_comm);
+void pcrs_dist_comm_destroy(void *nccl_comm);
+int pcrs_dist_sor_normals_dev(pcrs_ctx *ctx, void *nccl_comm, int rank, int world, const float *dx,
+                              const float *dy, const float *dz, size_t n_local, size_t n_total,
+                              uint32_t k_sor, float std_mul, uint32_t k_normals,
+                              const float viewpoint[3], size_t capacity, uint32_t *dpoint,
+                              uint8_t *dkeep, float *dmean, float *dnx, float *dny, float *dnz,
+                              pcrs_dist_sor_result *result);
+int pcrs_dist_icp_run(pcrs_icp *icp, void *nccl_comm, int rank, int world, size_t n_source_total,
+                      int mode, uint32_t max_iterations, float tolerance,
+                      float max_correspondence_distance, pcrs_icp_result *out);
+
 /* ------------------------------------------------------------ diagnostics */
 
 /* Benchmark instrumentation (no counterpart in the reference): when enabled,

@@ -1629,6 +1629,13 @@ struct pcrs_icp {
     DevBuf shard_seq;
 };
 
+pcrs_ctx *pcrs_icp_context(pcrs_icp *icp) { return icp ? icp->ctx : nullptr; }
+void pcrs_icp_lengths(const pcrs_icp *icp, size_t *n_source, size_t *n_target, size_t *n_normals) {
+    *n_source = icp->n;
+    *n_target = icp->m;
+    *n_normals = icp->n_normals;
+}
+
 namespace {
 
 // shared by find_correspondences and the ICP accumulate step

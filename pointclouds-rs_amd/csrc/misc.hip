@@ -373,6 +373,11 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const uint32_t *poin
     }
 }
 // out[point[i] - first] = value[i]
+__global__ __launch_bounds__(256) void index_run_kernel(uint32_t *out, size_t n, uint32_t first) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = first + (uint32_t)i;
+}
+
 __global__ __launch_bounds__(256) void scatter_offset_kernel(const float *in, const uint32_t *point,
                                                              size_t n, uint32_t first, float *out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -487,6 +492,14 @@ int pcrs_launch_scatter_offset(pcrs_ctx *ctx, const float *in, const uint32_t *p
     if (n == 0) return PCRS_OK;
     hipLaunchKernelGGL(scatter_offset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        ctx->stream, in, point, n, first, out);
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    return PCRS_OK;
+}
+
+int pcrs_launch_index_run(pcrs_ctx *ctx, uint32_t *out, size_t n, uint32_t first) {
+    if (n == 0) return PCRS_OK;
+    hipLaunchKernelGGL(index_run_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       out, n, first);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

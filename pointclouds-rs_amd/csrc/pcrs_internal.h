@@ -391,6 +391,8 @@ int pcrs_launch_select(pcrs_ctx *ctx, const float *x, const float *y, const floa
 // out[point[i] - first] = in[i]
 int pcrs_launch_scatter_offset(pcrs_ctx *ctx, const float *in, const uint32_t *point, size_t n,
                                uint32_t first, float *out);
+// out[i] = first + i
+int pcrs_launch_index_run(pcrs_ctx *ctx, uint32_t *out, size_t n, uint32_t first);
 // (point, value) pairs bucketed by the owner of the point's index range (see misc.hip)
 int pcrs_launch_route_pairs(pcrs_ctx *ctx, const uint32_t *point, const float *value, size_t n,
                             size_t n_total, uint32_t world, uint32_t *send_point, float *send_value,
@@ -483,6 +485,10 @@ int pcrs_launch_select_result(pcrs_ctx *ctx, const void *d_scalars,
 // build ended with (api.cpp)
 int pcrs_index_build_hinted_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
                                 size_t m, uint32_t k_hint, pcrs_index **out);
+
+// what the multi-GPU driver (dist.cpp) needs to know about an ICP handle (api.cpp)
+pcrs_ctx *pcrs_icp_context(pcrs_icp *icp);
+void pcrs_icp_lengths(const pcrs_icp *icp, size_t *n_source, size_t *n_target, size_t *n_normals);
 
 // ---- host math (host_math.cpp)
 void pcrs_host_compose(const float ra[9], const float ta[3], const float rb[9], const float tb[3],

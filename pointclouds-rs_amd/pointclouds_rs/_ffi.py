@@ -58,6 +58,13 @@ class ObstacleResultC(C.Structure):
                 ("sor_threshold", C.c_float)]
 
 
+class DistSorResultC(C.Structure):
+    _fields_ = [("n_answered", C.c_size_t), ("n_keep", C.c_size_t), ("n_escalated", C.c_size_t),
+                ("threshold", C.c_float), ("has_finite", C.c_int), ("by_slabs", C.c_int)]
+
+
+DIST_UNIQUE_ID_BYTES = 128
+
 # name -> (restype, argtypes); every symbol include/pcrs_hip.h declares
 _V = C.c_void_p
 _F3 = [_V, _V, _V]  # three column pointers (host or device)
@@ -144,6 +151,14 @@ SIGNATURES = {
     "pcrs_icp_shard_state": (C.c_int, [_V, C.POINTER(IcpResultC), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "pcrs_icp_shard_finish": (C.c_int, [_V]),
     "pcrs_icp_register": (C.c_int, [_V, C.c_int] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t] + _F3 + [C.c_size_t, C.c_uint32, C.c_float, C.c_float, C.POINTER(IcpResultC)]),
+    "pcrs_dist_unique_id": (C.c_int, [C.c_char_p]),
+    "pcrs_dist_comm_init": (C.c_int, [_V, C.c_char_p, C.c_int, C.c_int, C.POINTER(_V)]),
+    "pcrs_dist_comm_destroy": (None, [_V]),
+    "pcrs_dist_sor_normals_dev": (C.c_int, [_V, _V, C.c_int, C.c_int] + _F3 + [
+        C.c_size_t, C.c_size_t, C.c_uint32, C.c_float, C.c_uint32, c_float_p, C.c_size_t,
+        _V, _V, _V, _V, _V, _V, C.POINTER(DistSorResultC)]),
+    "pcrs_dist_icp_run": (C.c_int, [_V, _V, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_uint32,
+                                    C.c_float, C.c_float, C.POINTER(IcpResultC)]),
     "pcrs_index_last_stats": (C.c_int, [_V, C.POINTER(C.c_uint64)]),
     "pcrs_ctx_timing": (C.c_int, [_V, C.c_int]),
     "pcrs_ctx_timing_read": (C.c_int, [_V, c_f64_p, C.POINTER(C.c_uint64)]),

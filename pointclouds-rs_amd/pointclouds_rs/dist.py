@@ -331,6 +331,61 @@ class HipEngine:
     def icp_shard_finish(self, h):
         self.ctx.check(self.lib.pcrs_icp_shard_finish(h))
 
+    # -- the library's own multi-GPU driver (collectives on RCCL inside the call)
+    def dist_unique_id(self):
+        """The 128 bytes rank 0 hands to every rank of a new communicator."""
+        buf = C.create_string_buffer(_ffi.DIST_UNIQUE_ID_BYTES)
+        if self.lib.pcrs_dist_unique_id(buf) != 0:
+            raise _ffi.PcrsError(_ffi.PCRS_ERR_HIP, "RCCL is not available")
+        return buf.raw
+
+    def dist_comm_init(self, unique_id: bytes, rank: int, world: int):
+        comm = _V()
+        self.ctx.check(self.lib.pcrs_dist_comm_init(self.ctx.handle, unique_id, rank, world,
+                                                    C.byref(comm)))
+        return comm
+
+    def dist_comm_destroy(self, comm):
+        self.lib.pcrs_dist_comm_destroy(comm)
+
+    def dist_sor_normals(self, comm, rank, world, shard, n_total, k_sor, std_mul, k_nrm,
+                         viewpoint=(0.0, 0.0, 0.0), capacity=None, outputs=None):
+        """pcrs_dist_sor_normals_dev: the same result dict as sor_normals_sharded.  `outputs` may
+        carry preallocated tensors (point, mean, keep, nx, ny, nz) of one common length."""
+        n_local = shard[0].numel()
+        outputs = outputs or {}
+        cap = n_total if capacity is None else capacity
+        if "point" in outputs:
+            cap = min(t.numel() for t in outputs.values())
+
+        def buf(name, dtype="float32"):
+            t = outputs.get(name)
+            return t if t is not None else self.empty(cap, dtype)
+
+        point = buf("point", "int32")
+        mean = buf("mean") if k_sor else None
+        keep = buf("keep", "uint8") if k_sor else None
+        nx, ny, nz = (buf("nx"), buf("ny"), buf("nz")) if k_nrm else (None,) * 3
+        res = _ffi.DistSorResultC()
+        vp = (C.c_float * 3)(*viewpoint)
+        self.ctx.check(self.lib.pcrs_dist_sor_normals_dev(
+            self.ctx.handle, comm, rank, world, self._p(shard[0]), self._p(shard[1]),
+            self._p(shard[2]), n_local, n_total, k_sor, std_mul, k_nrm, vp, cap, self._p(point),
+            self._p(keep), self._p(mean), self._p(nx), self._p(ny), self._p(nz), C.byref(res)))
+        n = int(res.n_answered)
+        cut = lambda t: None if t is None else t[:n]
+        begin, end = shard_range(n_total, world, rank)
+        return dict(mean=cut(mean), keep=cut(keep), nx=cut(nx), ny=cut(ny), nz=cut(nz),
+                    point=cut(point), thr=float(res.threshold) if res.has_finite else math.nan,
+                    n_keep=int(res.n_keep), escalated=int(res.n_escalated), begin=begin, end=end,
+                    ownership="slabs" if res.by_slabs else "index", stats=None)
+
+    def dist_icp_run(self, h, comm, rank, world, n_source_total, mode, max_iter, tol, max_d):
+        res = _ffi.IcpResultC()
+        self.ctx.check(self.lib.pcrs_dist_icp_run(h, comm, rank, world, n_source_total, mode,
+                                                  max_iter, tol, max_d, C.byref(res)))
+        return res
+
     def compose(self, ra, ta, rb, tb):
         ro = (C.c_float * 9)()
         to = (C.c_float * 3)()

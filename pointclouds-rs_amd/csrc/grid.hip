@@ -569,6 +569,13 @@ struct CellArgs {
                             // refined index: what its cubes cannot certify is too sparse for its
                             // cells and is better served by the next coarser level's lanes)
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
+    // per-lane kernels: a query they cannot certify whose cube held fewer points than
+    // sparse_below (0: no such list) sits in a sparse spot of the cloud -- its neighbourhood spans
+    // many of this grid's cells and few of a coarser grid's -- and goes to sparse_list, for the
+    // lanes of the next coarser grid, instead of fail_list and this grid's wave-per-query kernel
+    uint32_t sparse_below;
+    uint32_t *sparse_list;
+    uint32_t *sparse_count;
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
     float *fail_bound;      // lane-per-query kernels, beside fail_list (nullable): an upper bound of
@@ -777,10 +784,10 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
         // now.  Otherwise it goes, flagged, to the wave-per-query kernel, which samples crowded
         // regions instead of walking them.
         uint32_t probe0 = 0, probe1 = 0;  // the slots the probe looked at (probe1 > probe0: answered by it)
+        uint32_t cube_pts = 0;
         {
             constexpr int RR = 1;  // cube half-width of this kernel
             const int x0 = max(cx - RR, 0), x1 = min(cx + RR, g.nx - 1);
-            uint32_t cube_pts = 0;
             constexpr int SIDE = 2 * RR + 1;
 #pragma unroll
             for (int i = 0; i < SIDE * SIDE; ++i) {
@@ -850,7 +857,9 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
             certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
         }
         if (!certified) {
-            if (a.fail_list) {
+            if (cube_pts < a.sparse_below) {
+                a.sparse_list[atomicAdd(a.sparse_count, 1u)] = qi;
+            } else if (a.fail_list) {
                 const uint32_t f = atomicAdd(a.fail_count, 1u);
                 a.fail_list[f] = qi;
                 if (a.fail_bound) a.fail_bound[f] = tau_cert;
@@ -1173,7 +1182,9 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
             certified = (m > 0.0f) && (tau_cert < (m * m) * (1.0f - 2e-6f));
         }
         if (!certified) {  // the retry starts from what this walk has seen
-            if (a.fail_list) {
+            if (ord < a.sparse_below) {
+                a.sparse_list[atomicAdd(a.sparse_count, 1u)] = qi;
+            } else if (a.fail_list) {
                 const uint32_t f = atomicAdd(a.fail_count, 1u);
                 a.fail_list[f] = qi;
                 if (a.fail_bound) a.fail_bound[f] = tau_cert;
@@ -2150,25 +2161,44 @@ __global__ __launch_bounds__(GB_THREADS) void radius_cell_kernel(CellArgs a, flo
 
 // Where a grid is crowded: the box (in cells) of the cells that hold more than `threshold` points,
 // as six maxima (the low sides stored as n - 1 - coordinate), their number and their points.
+// And where it is too sparse for its cells: short_points = the points whose own 27-cell cube holds
+// fewer than k_short points (no search of k_short neighbours can end in that cube).
 struct DenseScan {
     uint32_t hi[3], lo_rev[3];
     uint32_t cells, pad;
     unsigned long long points;
+    unsigned long long short_points;
 };
 __global__ __launch_bounds__(GB_THREADS) void dense_scan_kernel(const uint32_t *cell_start,
                                                                 GridGeom g, uint32_t ncell,
-                                                                uint32_t threshold, DenseScan *out) {
+                                                                uint32_t threshold, uint32_t k_short,
+                                                                DenseScan *out) {
     __shared__ uint32_t smax[6];
     __shared__ uint32_t scells;
-    __shared__ unsigned long long spoints;
+    __shared__ unsigned long long spoints, sshort;
     if (threadIdx.x < 6) smax[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         scells = 0;
         spoints = 0;
+        sshort = 0;
     }
     __syncthreads();
     for (uint32_t c = blockIdx.x * GB_THREADS + threadIdx.x; c < ncell; c += gridDim.x * GB_THREADS) {
         const uint32_t cnt = cell_start[c + 1] - cell_start[c];
+        if (cnt > 0u && cnt < k_short) {
+            const int cx = (int)(c % (uint32_t)g.nx), cy = (int)((c / (uint32_t)g.nx) % (uint32_t)g.ny);
+            const int cz = (int)(c / ((uint32_t)g.nx * (uint32_t)g.ny));
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            uint32_t cube = 0;
+            for (int i = 0; i < 9 && cube < k_short; ++i) {
+                const int yy = cy + i % 3 - 1, zz = cz + i / 3 - 1;
+                if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                    const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                    cube += cell_start[row + x1 + 1] - cell_start[row + x0];
+                }
+            }
+            if (cube < k_short) atomicAdd(&sshort, (unsigned long long)cnt);
+        }
         if (cnt > threshold) {
             const uint32_t cx = c % (uint32_t)g.nx, cy = (c / (uint32_t)g.nx) % (uint32_t)g.ny;
             const uint32_t cz = c / ((uint32_t)g.nx * (uint32_t)g.ny);
@@ -2189,6 +2219,7 @@ __global__ __launch_bounds__(GB_THREADS) void dense_scan_kernel(const uint32_t *
         atomicAdd(&out->cells, scells);
         atomicAdd(&out->points, spoints);
     }
+    if (threadIdx.x == 0 && sshort) atomicAdd(&out->short_points, sshort);
 }
 
 // Puts the points of every cell into ascending original-index order (one thread per cell; the
@@ -2456,7 +2487,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     // A caller that has just measured the cloud (the slab cut of a sharded run) brings bounds that
     // hold every point the index takes, and an upper limit of their number: no pass over the
     // columns for them, the exact count comes back with the first sort's statistics.
-    bool count_exact = !ix->have_bounds;
+    bool count_exact = !ix->have_bounds || ix->bounds_count_exact;
     if (ix->have_bounds) {
         for (int a = 0; a < 3; ++a) {
             lo[a] = ix->bounds_lo[a];
@@ -2826,6 +2857,76 @@ int pcrs_slab_cuts(pcrs_ctx *ctx, const float *x, const float *y, const float *z
     return PCRS_OK;
 }
 
+// Where the cells of a grid are crowded and where its cubes are short of points: one pass over the
+// cells, one read-back.
+static int scan_cells(pcrs_index *ix, uint32_t threshold, uint32_t k_short, DenseScan *out) {
+    pcrs_ctx *ctx = ix->ctx;
+    DevBuf d;
+    PCRS_HIP_CHECK(ctx, d.alloc(ctx, sizeof(DenseScan)));
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(d.p, 0, sizeof(DenseScan), ctx->stream));
+    hipLaunchKernelGGL(dense_scan_kernel, dim3(grid_for(ctx, ix->ncell, GB_THREADS)), dim3(GB_THREADS), 0,
+                       ctx->stream, ix->cell_start.as<uint32_t>(), ix->g, ix->ncell, threshold, k_short,
+                       d.as<DenseScan>());
+    void *pin = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(DenseScan) + 64, &pin));
+    PCRS_TRY(pcrs_launch_publish(ctx, d.p, pin, sizeof(DenseScan)));
+    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = *reinterpret_cast<const DenseScan *>(pin);
+    return PCRS_OK;
+}
+
+constexpr int kCoarseMaxDepth = 3;
+static bool coarse_enabled() {
+    static const bool on = [] {  // experiments only: PCRS_GRID_COARSE=0
+        const char *e = getenv("PCRS_GRID_COARSE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// A coarser grid behind `ix` when enough of its points sit in cubes that cannot hold their
+// neighbours (short_points of scan_cells), and another behind that one while the same holds there.
+static int grid_coarsen(pcrs_index *ix, uint32_t k_hint, unsigned long long short_points, int depth) {
+    pcrs_ctx *ctx = ix->ctx;
+    const GridGeom &g = ix->g;
+    if (!coarse_enabled() || depth >= kCoarseMaxDepth) return PCRS_OK;
+    if (short_points < std::max<unsigned long long>(8192, ix->nvalid / 64)) return PCRS_OK;
+    if (std::max(g.nx, std::max(g.ny, g.nz)) < 12) return PCRS_OK;  // a handful of cells already
+    pcrs_index *c = new (std::nothrow) pcrs_index();
+    if (!c) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+    c->ctx = ctx;
+    c->x = ix->x;
+    c->y = ix->y;
+    c->z = ix->z;
+    c->m = ix->m;
+    c->k_hint = k_hint;
+    c->box = ix->box;
+    // the same points: their bounds and number are known (no pass over the columns, no read-back)
+    const double o[3] = {g.ox, g.oy, g.oz};
+    const int n[3] = {g.nx, g.ny, g.nz};
+    c->have_bounds = true;
+    c->bounds_count_exact = true;
+    c->bounds_n_upper = ix->nvalid;
+    for (int a = 0; a < 3; ++a) {
+        c->bounds_lo[a] = o[a];
+        c->bounds_hi[a] = o[a] + (double)n[a] * (double)g.cell;
+    }
+    const int rc = pcrs_grid_build(c, k_hint, 3.0f * g.cell);
+    static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
+    if (debug)
+        fprintf(stderr, "pcrs grid coarse level %d: %llu of %zu points in cubes of fewer than %u points; "
+                        "coarser grid with cell %.5g (this level %.5g)\n",
+                depth + 1, short_points, ix->nvalid, k_hint, (double)c->g.cell, (double)g.cell);
+    if (rc != PCRS_OK || c->algo != PCRS_ALGO_GRID || !(c->g.cell > 1.5f * g.cell)) {
+        delete c;
+        return rc;
+    }
+    ix->coarse = c;
+    DenseScan ds{};
+    PCRS_TRY(scan_cells(c, 0xFFFFFFFFu, k_hint, &ds));
+    return grid_coarsen(c, k_hint, ds.short_points, depth + 1);
+}
+
 int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth) {
     pcrs_ctx *ctx = ix->ctx;
     if (!levels_enabled() || ix->algo != PCRS_ALGO_GRID || k_hint <= 1 || depth >= kLevelMaxDepth ||
@@ -2838,17 +2939,10 @@ int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth) {
     if (ix->occ_mean > 0.0 && ix->occ_seen < 2.0 * ix->occ_mean + 2.0) return PCRS_OK;
     const GridGeom &g = ix->g;
     const uint32_t threshold = (uint32_t)std::ceil(4.0 * ix->aim);
-    DevBuf d;
-    PCRS_HIP_CHECK(ctx, d.alloc(ctx, sizeof(DenseScan)));
-    PCRS_HIP_CHECK(ctx, hipMemsetAsync(d.p, 0, sizeof(DenseScan), ctx->stream));
-    hipLaunchKernelGGL(dense_scan_kernel, dim3(grid_for(ctx, ix->ncell, GB_THREADS)), dim3(GB_THREADS), 0,
-                       ctx->stream, ix->cell_start.as<uint32_t>(), g, ix->ncell, threshold,
-                       d.as<DenseScan>());
-    void *pin = nullptr;
-    PCRS_TRY(pcrs_ctx_pinned(ctx, sizeof(DenseScan) + 64, &pin));
-    PCRS_TRY(pcrs_launch_publish(ctx, d.p, pin, sizeof(DenseScan)));
-    PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const DenseScan ds = *reinterpret_cast<const DenseScan *>(pin);
+    const bool top = depth == 0 && ix->box.unbounded();
+    DenseScan ds{};
+    PCRS_TRY(scan_cells(ix, threshold, top ? k_hint : 0u, &ds));
+    if (top) PCRS_TRY(grid_coarsen(ix, k_hint, ds.short_points, 0));
     static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
     const size_t enough = std::max<size_t>(16384, ix->nvalid / 20);
     if (ds.cells == 0 || ds.points < enough) return PCRS_OK;
@@ -3043,6 +3137,7 @@ int pcrs_launch_normals_from_cov(pcrs_ctx *ctx, size_t nq, const float *cov, con
 pcrs_index::~pcrs_index() {
     delete whole;
     delete child;
+    delete coarse;
 }
 
 int pcrs_launch_scan_u32(pcrs_ctx *ctx, uint32_t *data, size_t n, uint32_t *sums,
@@ -3203,8 +3298,38 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     pcrs_ctx *ctx = top->ctx;
     KnnOut out = out_in;
     const uint32_t m = (uint32_t)top->m;
-    std::vector<pcrs_index *> levels;
-    for (pcrs_index *l = top; l; l = l->child) levels.push_back(l);
+    // the order the levels run in: the finer ones finest first, the index itself, the coarser ones
+    struct Level {
+        pcrs_index *ix;
+        bool own;          // has queries of its own (a coarser level only takes what it is handed)
+        BoxFilter in, ex;  // its queries: inside `in`, outside `ex`
+        bool pass_sparse;  // a coarser level follows: sparse failures skip this level's wave kernel
+    };
+    std::vector<Level> order;
+    {
+        std::vector<pcrs_index *> fine;
+        for (pcrs_index *l = top; l; l = l->child) fine.push_back(l);
+        for (int li = (int)fine.size() - 1; li >= 0; --li) {
+            Level v{};
+            v.ix = fine[li];
+            v.own = true;
+            v.in = li > 0 ? fine[li - 1]->child_qbox : pcrs_no_box();
+            if (fine[li]->child) {
+                v.ex = fine[li]->child_qbox;
+            } else {
+                for (int a3 = 0; a3 < 3; ++a3) v.ex.lo[a3] = v.ex.hi[a3] = 0.0f;  // excludes nothing
+            }
+            v.pass_sparse = li > 0 || top->coarse != nullptr;
+            order.push_back(v);
+        }
+        for (pcrs_index *c = top->coarse; c; c = c->coarse) {
+            Level v{};
+            v.ix = c;
+            v.own = false;
+            v.pass_sparse = c->coarse != nullptr;
+            order.push_back(v);
+        }
+    }
     const bool collect = out.idx || out.dist || out.count || out.nx;
     const uint32_t keff = kneed;  // every level holds far more points than a register list
     uint32_t kc = 0;
@@ -3220,8 +3345,9 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     }
     const bool timing_was = ctx->timing;
     const uint32_t *esc_list = nullptr, *esc_count = nullptr;  // what the finer level left
-    for (int li = (int)levels.size() - 1; li >= 0; --li) {
-        pcrs_index *ix = levels[li];
+    for (size_t li = 0; li < order.size(); ++li) {
+        const Level &lv = order[li];
+        pcrs_index *ix = lv.ix;
         const size_t list_elems = (size_t)m + 64;
         const size_t need = (5 * list_elems + 64) * sizeof(uint32_t);
         if (ix->fail_lists.bytes < need) PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
@@ -3244,17 +3370,15 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
                                (uint32_t)ix->nvalid, ix->spts3.as<float>());
         }
         // the level's own queries: inside its query box, outside the next finer level's
-        SlotChoice ch{};
-        ch.q_begin = 0;
-        ch.q_len = m;
-        ch.boxes = true;
-        ch.in = li > 0 ? levels[li - 1]->child_qbox : pcrs_no_box();
-        if (ix->child) {
-            ch.ex = ix->child_qbox;
-        } else {
-            for (int a3 = 0; a3 < 3; ++a3) ch.ex.lo[a3] = ch.ex.hi[a3] = 0.0f;  // excludes nothing
+        if (lv.own) {
+            SlotChoice ch{};
+            ch.q_begin = 0;
+            ch.q_len = m;
+            ch.boxes = true;
+            ch.in = lv.in;
+            ch.ex = lv.ex;
+            PCRS_TRY(choose_slots(ix, ch, listS, &counters[4]));
         }
-        PCRS_TRY(choose_slots(ix, ch, listS, &counters[4]));
 
         CellArgs a{};
         a.g = ix->g;
@@ -3276,6 +3400,10 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         a.useful_d2 = __builtin_inff();
         a.R = 1;
         a.heavy = m >= PCRS_HEAVY_FLAG ? 0xFFFFFFFFu : 8192u;
+        // a cube with fewer than three lists' worth of points that certifies nothing: a sparse spot
+        a.sparse_below = lv.pass_sparse ? 3u * keff : 0u;
+        a.sparse_list = listB;  // with what the wave kernel leaves: the next level's share
+        a.sparse_count = &counters[3];
         a.wave_radii[0] = 1;
         a.wave_radii[1] = 2;
         a.wave_radii[2] = 4;
@@ -3289,24 +3417,31 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         a.fail_bound = boundA;
         a.alt_list = listC;
         a.alt_count = &counters[5];
-        // stage 1 over the level's own queries ...
-        a.qmode = 3;
-        a.qlist = listS;
-        a.qcount = &counters[4];
         const unsigned lane_blocks = std::min((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS),
                                               (unsigned)ctx->num_cus * 64u);
-        pcrs_timing_begin(ctx);
-        launch_lane_kernel(ctx, a, out, kb, collect, lane_blocks);
-        pcrs_timing_end(ctx);
-        ix->counter_phase ^= 1;
-        a.zero_me = nullptr;
+        if (lv.own) {
+            // stage 1 over the level's own queries ...
+            a.qmode = 3;
+            a.qlist = listS;
+            a.qcount = &counters[4];
+            pcrs_timing_begin(ctx);
+            launch_lane_kernel(ctx, a, out, kb, collect, lane_blocks);
+            pcrs_timing_end(ctx);
+            ix->counter_phase ^= 1;
+            a.zero_me = nullptr;
+        }
         ctx->timing = false;
-        // ... and over what the finer level could not certify
+        // ... and over what the level before it could not certify (or passed on)
         if (esc_list) {
             a.qmode = 2;
             a.qlist = esc_list;
             a.qcount = esc_count;
-            launch_lane_kernel(ctx, a, out, kb, collect, (unsigned)ctx->num_cus * 4u);
+            launch_lane_kernel(ctx, a, out, kb, collect,
+                               lv.own ? (unsigned)ctx->num_cus * 4u : std::min(lane_blocks, (unsigned)ctx->num_cus * 16u));
+            if (a.zero_me) {  // a level without queries of its own: this was its first kernel
+                ix->counter_phase ^= 1;
+                a.zero_me = nullptr;
+            }
         }
         a.alt_list = nullptr;
         a.alt_count = nullptr;
@@ -3328,7 +3463,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
             const char *e = getenv("PCRS_GRID_PASS_UP");
             return e && e[0] == '1';
         }();
-        a.heavy_only = (pass_up && li > 0) ? 1u : 0u;
+        a.heavy_only = (pass_up && lv.own && lv.ix != top) ? 1u : 0u;
         launch_wave_kernel(ctx, a, out, kb, collect,
                            (unsigned)std::min<size_t>(((size_t)m + 3) / 4, (size_t)ctx->num_cus * 8));
         PCRS_HIP_CHECK(ctx, hipGetLastError());
@@ -3342,7 +3477,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
             uint32_t c[8];
             (void)hipMemcpyAsync(c, counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
-            fprintf(stderr, "pcrs search level %d (cell %.5g, %zu points): %u own queries, %u handed to the "
+            fprintf(stderr, "pcrs search level %zu (cell %.5g, %zu points): %u own queries, %u handed to the "
                             "two-walk kernel, %u left by the lanes, %u passed on\n",
                     li, (double)ix->g.cell, ix->nvalid, c[4], c[5], c[0], c[3]);
         }
@@ -3358,6 +3493,8 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     PCRS_TRY(rc_bf);
     if (top->nvalid < top->m)
         PCRS_TRY(pcrs_launch_invalid_defaults(ctx, top->x, top->y, top->z, q, out_in));
+    top->left_list = esc_list;
+    top->left_count = esc_count;
     top->stats_dev = top->counters.as<uint32_t>() + 16 * (top->counter_phase ^ 1);
     top->stats_nq = m;
     return PCRS_OK;
@@ -3383,7 +3520,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     }
     const bool nn_only = out.nn_idx && !out.idx && !out.dist && !out.count && !out.mean && !out.nx;
     const uint32_t nq = (uint32_t)q.nq;
-    if (ix->child && q.self && q.out_offset == 0 && q.nq == ix->m && !nn_only && !q.only_list &&
+    if ((ix->child || ix->coarse) && q.self && q.out_offset == 0 && q.nq == ix->m && !nn_only && !q.only_list &&
         !q.xform && keff == kneed)
         return launch_knn_levels(ix, q, out_in, kneed);
     // A pending increment of the queries (KnnQuery::xform) is applied by the 1-NN kernel as it

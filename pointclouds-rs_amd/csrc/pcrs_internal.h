@@ -181,6 +181,7 @@ struct pcrs_index {
     bool have_bounds = false;
     double bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
     size_t bounds_n_upper = 0;
+    bool bounds_count_exact = false;  // bounds_n_upper is the number of points, not a limit of it
     // grid (algo == GRID)
     GridGeom g{};
     size_t nvalid = 0;   // points in the grid: finite and inside the box
@@ -208,6 +209,11 @@ struct pcrs_index {
     // margin of one of this grid's cells more.
     pcrs_index *child = nullptr;
     BoxFilter child_qbox = pcrs_no_box();
+    // A coarser grid over the same points (cells three times as wide, itself with a coarser one
+    // where that is still too fine) for the sparse parts of a cloud of very uneven density: what
+    // this grid's lanes cannot certify because the query's cube held hardly any points goes to the
+    // coarser grid's lanes instead of this grid's wave-per-query kernel.
+    pcrs_index *coarse = nullptr;
     double aim = 0.0;  // points per occupied cell the build aimed at
     // of the accepted sort, when it read them back: mean points per occupied cell, and the
     // fullness of the cell the average point sits in (sum of squared counts / points - 1)

@@ -667,16 +667,18 @@ def run_frames(args):
 
     # the stages one by one through host buffers (as a caller of the reference's API runs them),
     # as a side figure; the frame itself goes through pcrs_obstacle_pipeline
-    for _ in range(max(args.warmup, 1)):
-        info_stages = frame_by_stages()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        info_stages = frame_by_stages()
-    dt_stages = time.perf_counter() - t0
+    info_stages, dt_stages = None, None
+    if not args.no_stages:
+        for _ in range(max(args.warmup, 1)):
+            info_stages = frame_by_stages()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            info_stages = frame_by_stages()
+        dt_stages = time.perf_counter() - t0
     frame = frame_one_call
     for _ in range(max(args.warmup, 1)):
         info = frame()
-    assert info == info_stages, (info, info_stages)
+    assert info_stages is None or info == info_stages, (info, info_stages)
     torch.cuda.synchronize()
     coll.barrier()
     t0 = time.perf_counter()
@@ -696,7 +698,7 @@ def run_frames(args):
                                    "(one upload, intermediate clouds on the device), replicas only (no "
                                    "collective)", "name": "c5",
                        "frame_rank0": dict(zip(("voxels", "kept", "ground", "clusters"), info)),
-                       "stage_by_stage_ms_rank0": dt_stages / args.steps * 1e3}}),
+                       "stage_by_stage_ms_rank0": None if dt_stages is None else dt_stages / args.steps * 1e3}}),
             flush=True)
     if world > 1:
         dist.destroy_process_group()

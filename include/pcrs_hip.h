@@ -604,6 +604,12 @@ int pcrs_ctx_timing_read(pcrs_ctx *ctx, double *total_ms, uint64_t *launches);
  * grid tile kernel, [1] by the ring-search fallback, [2] by brute force. */
 int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]);
 
+/* How many grids besides its own the index holds for clouds of very uneven density (no
+ * counterpart in the reference): *n_finer levels over the crowded part, each inside the one
+ * before, and *n_coarser grids of wider cells for the sparse part.  Both 0 for an evenly
+ * sampled cloud, a brute-force index or an index over a box. */
+int pcrs_index_levels(const pcrs_index *index, uint32_t *n_finer, uint32_t *n_coarser);
+
 #ifdef __cplusplus
 }
 #endif

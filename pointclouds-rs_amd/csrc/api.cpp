@@ -392,6 +392,14 @@ void pcrs_index_destroy(pcrs_index *index) try {
 
 size_t pcrs_index_len(const pcrs_index *index) { return index ? index->m : 0; }
 
+int pcrs_index_levels(const pcrs_index *index, uint32_t *n_finer, uint32_t *n_coarser) {
+    if (!index || !n_finer || !n_coarser) return PCRS_ERR_INVALID_ARG;
+    *n_finer = *n_coarser = 0;
+    for (const pcrs_index *l = index->child; l; l = l->child) ++*n_finer;
+    for (const pcrs_index *l = index->coarse; l; l = l->coarse) ++*n_coarser;
+    return PCRS_OK;
+}
+
 int pcrs_index_last_stats(const pcrs_index *index, uint64_t stats[3]) try {
     if (!index || !stats) return PCRS_ERR_INVALID_ARG;
     if (index->stats_dev) {

@@ -160,6 +160,7 @@ SIGNATURES = {
     "pcrs_dist_icp_run": (C.c_int, [_V, _V, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_uint32,
                                     C.c_float, C.c_float, C.POINTER(IcpResultC)]),
     "pcrs_index_last_stats": (C.c_int, [_V, C.POINTER(C.c_uint64)]),
+    "pcrs_index_levels": (C.c_int, [_V, c_u32_p, c_u32_p]),
     "pcrs_ctx_timing": (C.c_int, [_V, C.c_int]),
     "pcrs_ctx_timing_read": (C.c_int, [_V, c_f64_p, C.POINTER(C.c_uint64)]),
 }

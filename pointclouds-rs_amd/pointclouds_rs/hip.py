@@ -133,6 +133,12 @@ class Index:
         self.ctx.check(self.ctx.lib.pcrs_index_last_stats(self.handle, s))
         return {"grid_tile": int(s[0]), "grid_ring": int(s[1]), "brute": int(s[2])}
 
+    def levels(self):
+        """(finer, coarser): the grids besides its own that the index holds for uneven clouds."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self.ctx.check(self.ctx.lib.pcrs_index_levels(self.handle, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
 
 def sor(x, y, z, k, std_mul, device=0):
     """statistical_outlier_removal on columns: (keep[n] bool, n_keep, threshold, mean[n])."""

@@ -1077,8 +1077,8 @@ def test_slab_indexes_partition_the_cloud_and_match_the_oracle(oracle, world):
             assert escalated > 0  # the small halo does send queries to the whole-cloud index
 
 
-@pytest.mark.parametrize("cloud", ["rings", "blob"])
-def test_clouds_of_very_uneven_density_use_finer_levels_and_match_the_oracle(hip, oracle, cloud):
+@pytest.mark.parametrize("cloud", ["rings", "blob", "rings4"])
+def test_clouds_of_very_uneven_density_use_finer_and_coarser_levels_and_match_the_oracle(hip, oracle, cloud):
     """A spinning-LiDAR shaped scan (density falling by a factor of hundreds from the sensor
     outwards) and a millimetre blob in a box 200 units wide: the index gives the crowded part
     finer grids of its own, every point is answered at the finest level that holds it, and what
@@ -1086,6 +1086,11 @@ def test_clouds_of_very_uneven_density_use_finer_levels_and_match_the_oracle(hip
     be the oracle's; the normals within 1e-5."""
     if cloud == "rings":
         x, y, z = gen.ring_scan(1)          # 131 072 points
+        vp = (0.0, 0.0, 1.73)
+    elif cloud == "rings4":
+        # four sweeps: enough points far out, in cubes that cannot hold their neighbours, for the
+        # index to add a grid of wider cells behind its own
+        x, y, z = gen.ring_scan(4)          # 524 288 points
         vp = (0.0, 0.0, 1.73)
     else:
         x, y, z = gen.blob_in_box(30_000, 50_000)
@@ -1105,6 +1110,8 @@ def test_clouds_of_very_uneven_density_use_finer_levels_and_match_the_oracle(hip
     assert normals_close(got, ref5, 1e-5).mean() > 0.999
     # explicit queries are answered by the coarsest grid alone (crowded cubes by the wave kernel)
     ix = hip.Index(x, y, z, k_hint=k + 1)
+    finer, coarser = ix.levels()
+    assert finer >= 1 and (coarser >= 1 or cloud != "rings4"), (finer, coarser)
     q = np.random.default_rng(2).choice(len(x), 3000, replace=False)
     idx, dist, cnt = ix.knn(x[q], y[q], z[q], k + 1)
     ix.close()

@@ -476,6 +476,11 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
     const int lane = threadIdx.x;
     const float mu = (PASS == 2) ? sc->mu : 0.0f;
     float s = chunk_begin ? sc->run : 0.0f;  // uniform across the wave
+#ifdef PCRS_STATS_TRACE
+    const long long tr_start = wall_clock64();
+    long long tr_staged = tr_start, tr_elem = 0, tr_scan = 0;
+    unsigned tr_nelem = 0, tr_nscan = 0, tr_nwhole = 0;
+#endif
     if constexpr (STAGE) {
         // Staging is done by the whole block (ST_STAGE_THREADS threads: every load of a phase in
         // flight at once); the walk that follows is the first wave's alone.
@@ -535,6 +540,9 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
         __syncthreads();
         if (tid >= 64u) return;
     }
+#ifdef PCRS_STATS_TRACE
+    tr_staged = wall_clock64();
+#endif
     // the composites of the next batch are requested while the current one is being scanned
     auto load_batch = [&](uint32_t base, Composite (&dst)[G][W]) {
 #pragma unroll
@@ -611,6 +619,9 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
             // the sum only grows: in the binade after the batch = in the binade throughout
             if (inc < ST_SAT && S + inc < (1u << 24)) {
                 s = __uint_as_float((bits & 0xFF800000u) | ((S + inc) & 0x7FFFFFu));
+#ifdef PCRS_STATS_TRACE
+                ++tr_nwhole;
+#endif
                 continue;
             }
         }
@@ -619,6 +630,10 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
         const uint32_t lim = min(BATCH, nchunks - base);
         uint32_t pos = 0;
         while (pos < lim) {
+#ifdef PCRS_STATS_TRACE
+            const long long tr_a = wall_clock64();
+            ++tr_nscan;
+#endif
             const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
             const int e_now = binade_of(__uint_as_float(bits));
             const uint32_t S = (bits & 0x7FFFFFu) | 0x800000u;
@@ -691,7 +706,14 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
                 const uint32_t Sj = __builtin_amdgcn_readlane(sel, j / G);
                 s = __uint_as_float((bits & 0xFF800000u) | (Sj & 0x7FFFFFu));
             }
+#ifdef PCRS_STATS_TRACE
+            const long long tr_b = wall_clock64();
+            tr_scan += tr_b - tr_a;
+#endif
             if (first_bad < lim) {
+#ifdef PCRS_STATS_TRACE
+                ++tr_nelem;
+#endif
                 // element-by-element f32 adds over this chunk (lane-major element order)
                 const uint32_t bad_chunk = base + first_bad;
                 float4 mine4;
@@ -718,9 +740,18 @@ __global__ __launch_bounds__(STAGE ? ST_STAGE_THREADS : 64) void stats_walk_kern
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+#ifdef PCRS_STATS_TRACE
+            tr_elem += wall_clock64() - tr_b;
+#endif
             pos = first_bad + 1;
         }
     }
+#ifdef PCRS_STATS_TRACE
+    if (lane == 0)
+        printf("walk pass %d: staging %lld, walk %lld ticks (100 MHz); %u whole batches, %u scans (%lld ticks), "
+               "%u element-wise chunks (%lld ticks)\n", PASS, tr_staged - tr_start, wall_clock64() - tr_staged,
+               tr_nwhole, tr_nscan, tr_scan, tr_nelem, tr_elem);
+#endif
     if (lane == 0) sc->run = s;
     if (lane == 0 && last) {
         const float nn = (float)sc->nf;  // finite_dists.len() as f32

@@ -145,3 +145,131 @@ def test_icp_argument_checks(eng_comm):
             eng.dist_icp_run(h, comm, 0, 1, 501, 0, 5, 0.0, float("inf"))
     finally:
         eng.icp_destroy(h)
+
+
+# ---- two ranks, two processes: on two GPUs where the machine has them, else both on the one GPU
+# (which RCCL may refuse: the test is then skipped)
+
+def _cloud2():
+    from pointclouds_rs import synth
+
+    return synth.kitti_scene(3, 51001, 2000, 1000)  # 58001 points: uneven shards
+
+
+def _rank(rank, world, q_id, q_out, icp_inputs):
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(os.path.dirname(here), "pointclouds-rs_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+
+    from pointclouds_rs import _ffi
+    from pointclouds_rs.dist import HipEngine, shard_range
+
+    # a GPU of its own where the machine has one for every rank (then RCCL really runs between
+    # devices); on a one-GPU box both ranks take device 0, which RCCL may refuse
+    eng = HipEngine.shared(rank if torch.cuda.device_count() >= world else 0)
+    if rank == 0:
+        uid = eng.dist_unique_id()
+        for _ in range(world - 1):
+            q_id.put(uid)
+    else:
+        uid = q_id.get(timeout=60)
+    try:
+        comm = eng.dist_comm_init(uid, rank, world)
+    except _ffi.PcrsError as ex:
+        q_out.put(dict(rank=rank, refused=str(ex)))
+        return
+    x, y, z = _cloud2()
+    n = len(x)
+    b, e = shard_range(n, world, rank)
+    shard = [eng.from_numpy(c[b:e]) for c in (x, y, z)]
+    r = eng.dist_sor_normals(comm, rank, world, shard, n, 16, 1.0, 16)
+    torch.cuda.synchronize()
+    out = dict(rank=rank, ownership=r["ownership"], thr=r["thr"], n_keep=r["n_keep"],
+               point=r["point"].cpu().numpy().view(np.uint32).copy(), mean=r["mean"].cpu().numpy().copy(),
+               keep=r["keep"].cpu().numpy().copy(),
+               normals=[r[c].cpu().numpy().copy() for c in ("nx", "ny", "nz")])
+    inp = np.load(icp_inputs)
+    S = [inp["s%d" % a] for a in range(3)]
+    sb, se = shard_range(len(S[0]), world, rank)
+    d_src = [eng.from_numpy(np.ascontiguousarray(c[sb:se])) for c in S]
+    d_tgt = [eng.from_numpy(inp["t%d" % a]) for a in range(3)]
+    d_tn = [eng.from_numpy(inp["n%d" % a]) for a in range(3)]
+    h = eng.icp_create(d_src, d_tgt, d_tn)
+    try:
+        for name, max_iter, tol in (("icp", 12, 0.0), ("icp_tol", 30, 1e-4)):
+            res = eng.dist_icp_run(h, comm, rank, world, len(S[0]), 1, max_iter, tol, float("inf"))
+            out[name] = dict(rot=list(res.rotation), t=list(res.translation), rmse=float(res.rmse),
+                             fitness=float(res.fitness), iters=int(res.num_iterations),
+                             converged=bool(res.converged))
+    finally:
+        eng.icp_destroy(h)
+    q_out.put(out)
+    eng.dist_comm_destroy(comm)
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_exchange_like_the_oracle_says(oracle, tmp_path):
+    """The exchange between ranks (routing of the means, gathers, the ICP sums) with two
+    processes.  A RCCL that refuses two ranks on one GPU skips the test on a one-GPU box."""
+    import queue
+
+    import torch.multiprocessing as mp
+    from pointclouds_rs import synth
+
+    world = 2
+    tgt = synth.hemisphere(4000, 99, 5.0)
+    tn = oracle.normals(*tgt, 12, algo=1)
+    src = oracle.apply_transform(*tgt, synth.rot_z(0.04), (0.2, -0.1, 0.05))
+    icp_inputs = str(tmp_path / "icp_inputs.npz")
+    np.savez(icp_inputs, **{"s%d" % a: src[a] for a in range(3)},
+             **{"t%d" % a: tgt[a] for a in range(3)}, **{"n%d" % a: tn[a] for a in range(3)})
+    ctx = mp.get_context("spawn")
+    q_id, q_out = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_rank, args=(r, world, q_id, q_out, icp_inputs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = []
+    try:
+        for _ in range(200):
+            try:
+                outs.append(q_out.get(timeout=1.0))
+            except queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
+            if len(outs) == world:
+                break
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+    if any("refused" in o for o in outs):
+        pytest.skip("RCCL does not put two ranks on one device: " + str([o.get("refused") for o in outs]))
+    assert len(outs) == world, [p.exitcode for p in procs]
+    outs.sort(key=lambda d: d["rank"])
+    x, y, z = _cloud2()
+    keep, n_keep, thr, mean = oracle.sor(x, y, z, 16, 1.0, algo=1)
+    rn = oracle.normals(x, y, z, 16, algo=1)
+    assert sum(o["n_keep"] for o in outs) == n_keep
+    for o in outs:
+        pt = o["point"]
+        assert o["ownership"] == "slabs"
+        assert F(o["thr"]).view(np.uint32) == F(thr).view(np.uint32)
+        assert np.array_equal(o["mean"].view(np.uint32), mean[pt].view(np.uint32))
+        assert np.array_equal(o["keep"].astype(bool), keep[pt])
+        for got, ref in zip(o["normals"], rn):
+            assert np.abs(got.astype(np.float64) - ref[pt]).max() <= 1e-5
+    assert np.array_equal(np.sort(np.concatenate([o["point"] for o in outs])), np.arange(len(x)))
+    for name, max_iter, tol in (("icp", 12, 0.0), ("icp_tol", 30, 1e-4)):
+        rc, ref, _ = oracle.icp(1, src, tgt, tn, max_iter=max_iter, tol=tol, algo=1)
+        assert outs[0][name] == outs[1][name]  # bit for bit the same on both ranks
+        got = outs[0][name]
+        assert got["iters"] == ref.num_iterations and got["converged"] == bool(ref.converged)
+        assert got["fitness"] == ref.fitness and got["rmse"] == ref.rmse
+        assert np.allclose(got["rot"], list(ref.rot), rtol=0, atol=2.5e-7)
+        assert np.allclose(got["t"], list(ref.t), rtol=0, atol=2.5e-7)

@@ -212,7 +212,7 @@ def test_c3_point_to_point_100k_vs_literal_oracle(oracle):
     """Point-to-point ICP at the size of the benchmark's registration against the oracle's LITERAL
     restatement of icp.rs:210-270 (centroids and cross-covariance summed left to right in f32).
     The library sums in f64, so the two differ by the rounding noise of the reference's own f32
-    sums over 100 K terms; the deviation measured here is what DESIGN.md quotes.  Loop control
+    sums over 100 K terms; the deviation is measured here and written to a file.  Loop control
     must still agree."""
     from pointclouds_rs import hip, synth
 
@@ -234,8 +234,8 @@ def test_c3_point_to_point_100k_vs_literal_oracle(oracle):
     assert np.allclose(np.array(res.rotation), np.array(twin.rot), rtol=0, atol=2.5e-7)
     assert np.allclose(np.array(res.translation), np.array(twin.t), rtol=0, atol=2.5e-7)
     assert F(res.rmse).view(np.uint32) == F(twin.rmse).view(np.uint32)
-    # the literal f32 arithmetic: bounded by the noise of its own sums
-    assert dr <= 2e-4 and dt <= 5e-4
+    # the literal f32 arithmetic: bounded by the noise of its own sums (measured 9e-7 and 1.1e-5)
+    assert dr <= 5e-6 and dt <= 5e-5 and drmse <= 1e-5
     import os
 
     os.makedirs("gpurun_out", exist_ok=True)

@@ -87,6 +87,12 @@ void shard_range(size_t n, int world, int r, size_t *b, size_t *e) {
 int all_gather_var(pcrs_ctx *ctx, ncclComm_t comm, int rank, int world, const void *mine,
                    void *all, const std::vector<size_t> &counts, size_t elem, ncclDataType_t type) {
     const Rccl &r = rccl();
+    bool equal = true;
+    for (int p = 1; p < world; ++p) equal = equal && counts[(size_t)p] == counts[0];
+    if (equal) {  // the plain collective (in place when the piece already lies in its place)
+        if (counts[0]) PCRS_NCCL(ctx, r.AllGather(mine, all, counts[0], type, comm, ctx->stream));
+        return PCRS_OK;
+    }
     PCRS_NCCL(ctx, r.GroupStart());
     size_t off = 0;
     for (int p = 0; p < world; ++p) {

@@ -3329,6 +3329,11 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
             v.pass_sparse = c->coarse != nullptr;
             order.push_back(v);
         }
+        // a sparse spot of one level is only handed to the next when that one is the next size up
+        // (a millimetre blob in a scene of metres has levels a thousand times apart: the rim of
+        // the blob, sparse by the blob's measure, would meet the whole blob in one cell there)
+        for (size_t i = 0; i + 1 < order.size(); ++i)
+            if (order[i + 1].ix->g.cell > 4.5f * order[i].ix->g.cell) order[i].pass_sparse = false;
     }
     const bool collect = out.idx || out.dist || out.count || out.nx;
     const uint32_t keff = kneed;  // every level holds far more points than a register list

@@ -43,7 +43,7 @@ HBM_PEAK_GBPS = 8000.0
 VALU_PEAK_TOPS = 78.6
 N_XCD, N_SIMD = 8, 1024  # MI355X: 8 XCDs, 256 CUs x 4 SIMDs
 METRIC = "Mpoints/sec through SOR k=16 + normals on 1M-pt cloud; ICP iters/sec"
-PROFILE_TAG = "r02d"
+PROFILE_TAG = "r03"
 SEARCH_KERNEL = "knn_tag_kernel<17>"  # the dominant kernel of the default workload
 
 

@@ -570,12 +570,14 @@ struct CellArgs {
                             // cells and is better served by the next coarser level's lanes)
     uint32_t heavy;         // per-lane kernels hand cubes with more points than this to a wave
     // per-lane kernels: a query they cannot certify whose cube held fewer points than
-    // sparse_below (0: no such list) sits in a sparse spot of the cloud -- its neighbourhood spans
-    // many of this grid's cells and few of a coarser grid's -- and goes to sparse_list, for the
-    // lanes of the next coarser grid, instead of fail_list and this grid's wave-per-query kernel
+    // sparse_below (0: never) sits in a sparse spot of the cloud -- its neighbourhood spans many of
+    // this grid's cells and few of a coarser grid's --
+    // and is marked for the lanes of the next coarser grid (hand_flags[query] = hand_level, a byte
+    // per point of the cloud) instead of joining fail_list and this grid's wave-per-query kernel.
+    // The wave-per-query kernel marks what it cannot certify the same way when hand_flags is set.
     uint32_t sparse_below;
-    uint32_t *sparse_list;
-    uint32_t *sparse_count;
+    uint8_t *hand_flags;
+    uint8_t hand_level;
     uint32_t *fail_list;    // queries that could not be certified (as indices into qx/qy/qz)
     uint32_t *fail_count;
     float *fail_bound;      // lane-per-query kernels, beside fail_list (nullable): an upper bound of
@@ -858,7 +860,7 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
         }
         if (!certified) {
             if (cube_pts < a.sparse_below) {
-                a.sparse_list[atomicAdd(a.sparse_count, 1u)] = qi;
+                a.hand_flags[qi] = a.hand_level;
             } else if (a.fail_list) {
                 const uint32_t f = atomicAdd(a.fail_count, 1u);
                 a.fail_list[f] = qi;
@@ -1183,7 +1185,7 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
         }
         if (!certified) {  // the retry starts from what this walk has seen
             if (ord < a.sparse_below) {
-                a.sparse_list[atomicAdd(a.sparse_count, 1u)] = qi;
+                a.hand_flags[qi] = a.hand_level;
             } else if (a.fail_list) {
                 const uint32_t f = atomicAdd(a.fail_count, 1u);
                 a.fail_list[f] = qi;
@@ -1414,7 +1416,10 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
         const uint32_t qi = entry & ~PCRS_HEAVY_FLAG;
         const int first_radius = (entry & PCRS_HEAVY_FLAG) ? 0 : 1;
         if (a.heavy_only && !(entry & PCRS_HEAVY_FLAG)) {
-            if (lane == 0 && a.fail_list) a.fail_list[atomicAdd(a.fail_count, 1u)] = qi;
+            if (lane == 0) {
+                if (a.hand_flags) a.hand_flags[qi] = a.hand_level;
+                else if (a.fail_list) a.fail_list[atomicAdd(a.fail_count, 1u)] = qi;
+            }
             continue;
         }
         const float qx = a.qx[qi], qy = a.qy[qi], qz = a.qz[qi];  // finite: stage 1 filtered
@@ -1655,9 +1660,13 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             }
         }
         if (failed) {
-            if (lane == 0 && a.fail_list) {
-                const uint32_t f = atomicAdd(a.fail_count, 1u);
-                a.fail_list[f] = qi;
+            if (lane == 0) {
+                if (a.hand_flags) {
+                    a.hand_flags[qi] = a.hand_level;
+                } else if (a.fail_list) {
+                    const uint32_t f = atomicAdd(a.fail_count, 1u);
+                    a.fail_list[f] = qi;
+                }
             }
             continue;
         }
@@ -1711,10 +1720,16 @@ constexpr int OWN_BLOCK = GB_THREADS * OWN_PER_THREAD;
 // Which sorted slots are queries: original index in [q_begin, q_begin + q_len) and, with boxes,
 // inside `in` but not inside `ex` (a slab of a sharded cloud; a level of a refined index without
 // the part the next level answers).
+// handed (nullable): a byte per point of the columns; a point whose byte equals `level` is a query
+// too, whatever the boxes say (a level of a refined index: what the level before it passed on).
+// no_own: only those.
 struct SlotChoice {
     uint32_t q_begin, q_len;
     bool boxes;
     BoxFilter in, ex;
+    const uint8_t *handed;
+    uint8_t level;
+    bool no_own;
 };
 __device__ __forceinline__ uint32_t owned_flags(const float4 *spts, uint32_t nvalid, uint32_t first,
                                                 const SlotChoice &ch) {
@@ -1724,9 +1739,10 @@ __device__ __forceinline__ uint32_t owned_flags(const float4 *spts, uint32_t nva
         const uint32_t s = first + i;
         if (s < nvalid) {
             const float4 p = spts[s];
-            bool own = (__float_as_uint(p.w) - ch.q_begin) < ch.q_len;
+            bool own = (__float_as_uint(p.w) - ch.q_begin) < ch.q_len && !ch.no_own;
             if (ch.boxes)
                 own = own && point_taken(ch.in, p.x, p.y, p.z) && !point_taken(ch.ex, p.x, p.y, p.z);
+            if (ch.handed) own = own || ch.handed[__float_as_uint(p.w)] == ch.level;
             if (own) f |= 1u << i;
         }
     }
@@ -2911,7 +2927,12 @@ static int grid_coarsen(pcrs_index *ix, uint32_t k_hint, unsigned long long shor
         c->bounds_lo[a] = o[a];
         c->bounds_hi[a] = o[a] + (double)n[a] * (double)g.cell;
     }
-    const int rc = pcrs_grid_build(c, k_hint, 3.0f * g.cell);
+    static const float coarse_ratio = [] {  // experiments only: PCRS_GRID_COARSE_RATIO
+        const char *e = getenv("PCRS_GRID_COARSE_RATIO");
+        const float v = e ? (float)atof(e) : 0.0f;
+        return v >= 1.6f && v <= 8.0f ? v : 3.0f;
+    }();
+    const int rc = pcrs_grid_build(c, k_hint, coarse_ratio * g.cell);
     static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
     if (debug)
         fprintf(stderr, "pcrs grid coarse level %d: %llu of %zu points in cubes of fewer than %u points; "
@@ -3349,10 +3370,19 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         out.cov = cov.as<float>();
     }
     const bool timing_was = ctx->timing;
-    const uint32_t *esc_list = nullptr, *esc_count = nullptr;  // what the finer level left
+    // What a level passes on is marked in a byte per point (the number of the level it is meant
+    // for): the next level picks the marked points up together with its own queries, in the order
+    // of its own cells -- neighbouring lanes then walk neighbouring cubes, which a list in the
+    // order of the failures would not give them.
+    if (order.size() > 255) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "too many grid levels");
+    if (top->hand_flags.bytes < (size_t)m + 64) PCRS_HIP_CHECK(ctx, top->hand_flags.alloc(ctx, (size_t)m + 64));
+    uint8_t *hand = top->hand_flags.as<uint8_t>();
+    if (order.size() > 1) PCRS_HIP_CHECK(ctx, hipMemsetAsync(hand, 0, m, ctx->stream));
+    const uint32_t *esc_list = nullptr, *esc_count = nullptr;  // what the last level left
     for (size_t li = 0; li < order.size(); ++li) {
         const Level &lv = order[li];
         pcrs_index *ix = lv.ix;
+        const bool last_level = li + 1 == order.size();
         const size_t list_elems = (size_t)m + 64;
         const size_t need = (5 * list_elems + 64) * sizeof(uint32_t);
         if (ix->fail_lists.bytes < need) PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
@@ -3374,14 +3404,18 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
                                dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(),
                                (uint32_t)ix->nvalid, ix->spts3.as<float>());
         }
-        // the level's own queries: inside its query box, outside the next finer level's
-        if (lv.own) {
+        // the level's queries: its own (inside its query box, outside the next finer level's)
+        // and what the level before it marked for it
+        {
             SlotChoice ch{};
             ch.q_begin = 0;
             ch.q_len = m;
             ch.boxes = true;
             ch.in = lv.in;
             ch.ex = lv.ex;
+            ch.no_own = !lv.own;
+            ch.handed = li > 0 ? hand : nullptr;
+            ch.level = (uint8_t)li;
             PCRS_TRY(choose_slots(ix, ch, listS, &counters[4]));
         }
 
@@ -3406,9 +3440,9 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         a.R = 1;
         a.heavy = m >= PCRS_HEAVY_FLAG ? 0xFFFFFFFFu : 8192u;
         // a cube with fewer than three lists' worth of points that certifies nothing: a sparse spot
-        a.sparse_below = lv.pass_sparse ? 3u * keff : 0u;
-        a.sparse_list = listB;  // with what the wave kernel leaves: the next level's share
-        a.sparse_count = &counters[3];
+        a.sparse_below = (lv.pass_sparse && !last_level) ? 3u * keff : 0u;
+        a.hand_flags = last_level ? nullptr : hand;
+        a.hand_level = (uint8_t)(li + 1);
         a.wave_radii[0] = 1;
         a.wave_radii[1] = 2;
         a.wave_radii[2] = 4;
@@ -3424,30 +3458,17 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         a.alt_count = &counters[5];
         const unsigned lane_blocks = std::min((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS),
                                               (unsigned)ctx->num_cus * 64u);
-        if (lv.own) {
-            // stage 1 over the level's own queries ...
-            a.qmode = 3;
-            a.qlist = listS;
-            a.qcount = &counters[4];
-            pcrs_timing_begin(ctx);
-            launch_lane_kernel(ctx, a, out, kb, collect, lane_blocks);
-            pcrs_timing_end(ctx);
-            ix->counter_phase ^= 1;
-            a.zero_me = nullptr;
-        }
+        // stage 1 over the level's queries
+        a.qmode = 3;
+        a.qlist = listS;
+        a.qcount = &counters[4];
+        pcrs_timing_begin(ctx);
+        launch_lane_kernel(ctx, a, out, kb, collect,
+                           lv.own ? lane_blocks : std::min(lane_blocks, (unsigned)ctx->num_cus * 16u));
+        pcrs_timing_end(ctx);
+        ix->counter_phase ^= 1;
+        a.zero_me = nullptr;
         ctx->timing = false;
-        // ... and over what the level before it could not certify (or passed on)
-        if (esc_list) {
-            a.qmode = 2;
-            a.qlist = esc_list;
-            a.qcount = esc_count;
-            launch_lane_kernel(ctx, a, out, kb, collect,
-                               lv.own ? (unsigned)ctx->num_cus * 4u : std::min(lane_blocks, (unsigned)ctx->num_cus * 16u));
-            if (a.zero_me) {  // a level without queries of its own: this was its first kernel
-                ix->counter_phase ^= 1;
-                a.zero_me = nullptr;
-            }
-        }
         a.alt_list = nullptr;
         a.alt_count = nullptr;
         if (one_walk) {
@@ -3482,8 +3503,9 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
             uint32_t c[8];
             (void)hipMemcpyAsync(c, counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
-            fprintf(stderr, "pcrs search level %zu (cell %.5g, %zu points): %u own queries, %u handed to the "
-                            "two-walk kernel, %u left by the lanes, %u passed on\n",
+            fprintf(stderr, "pcrs search level %zu (cell %.5g, %zu points): %u queries (its own and what the "
+                            "level before marked for it), %u handed to the two-walk kernel, %u left by the "
+                            "lanes to the wave kernel, %u left for brute force (last level)\n",
                     li, (double)ix->g.cell, ix->nvalid, c[4], c[5], c[0], c[3]);
         }
     }

@@ -214,6 +214,9 @@ struct pcrs_index {
     // this grid's lanes cannot certify because the query's cube held hardly any points goes to the
     // coarser grid's lanes instead of this grid's wave-per-query kernel.
     pcrs_index *coarse = nullptr;
+    // a byte per point of the columns, for a search over the chain of grids: the level a query
+    // that one level could not answer is meant for next
+    DevBuf hand_flags;
     double aim = 0.0;  // points per occupied cell the build aimed at
     // of the accepted sort, when it read them back: mean points per occupied cell, and the
     // fullness of the cell the average point sits in (sum of squared counts / points - 1)

@@ -76,6 +76,94 @@ __global__ __launch_bounds__(64) void radix_scatter_kernel(const uint64_t *keys,
     }
 }
 
+// The whole sort of a short array in ONE launch: a single workgroup of sixteen waves runs every
+// pass -- each wave owns a contiguous sixteenth of the array, counts its digits into its own row of
+// an LDS table, the table is scanned digit-major (so the passes stay stable), and the wave scatters
+// its part with the ballot ranking of radix_scatter_kernel.  Three launches a pass cost a frame of
+// a LiDAR (four sorts of 2-3 passes over 2-57 K keys) more than the sorting itself.
+constexpr uint32_t RS_SMALL_MAX = 8192;
+constexpr int RS_SMALL_WAVES = 16;
+
+__global__ __launch_bounds__(RS_SMALL_WAVES * 64) void radix_sort_small_kernel(
+    uint64_t *k0, uint32_t *v0, uint64_t *k1, uint32_t *v1, uint32_t n, int key_bits) {
+    __shared__ uint32_t cur[RS_SMALL_WAVES][256];
+    __shared__ uint32_t wave_total[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t per = (((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES) + 63u) & ~63u;
+    const uint32_t begin = min(n, (uint32_t)w * per), end = min(n, begin + per);
+    uint64_t *kin = k0, *kout = k1;
+    uint32_t *vin = v0, *vout = v1;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        for (int t = lane; t < 256; t += 64) cur[w][t] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t i = begin + lane; i < end; i += 64)
+            atomicAdd(&cur[w][(uint32_t)(kin[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        // first slot of every (digit, wave): digits in order, the waves of a digit in order
+        uint32_t total = 0, incl = 0;
+        if (threadIdx.x < 256) {
+            for (int j = 0; j < RS_SMALL_WAVES; ++j) total += cur[j][threadIdx.x];
+            incl = total;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) wave_total[w] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t run = incl - total;
+            for (int j = 0; j < w; ++j) run += wave_total[j];
+            for (int j = 0; j < RS_SMALL_WAVES; ++j) {
+                const uint32_t c = cur[j][threadIdx.x];
+                cur[j][threadIdx.x] = run;
+                run += c;
+            }
+        }
+        __syncthreads();
+        for (uint32_t base = begin; base < end; base += 64) {
+            const uint32_t i = base + lane;
+            const bool live = i < end;
+            uint64_t key = 0;
+            uint32_t val = 0;
+            if (live) {
+                key = kin[i];
+                if (vin) val = vin[i];
+            }
+            const uint32_t digit = (uint32_t)(key >> shift) & 255u;
+            unsigned long long peers = __ballot(live);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long set = __ballot((digit >> b) & 1u);
+                peers &= ((digit >> b) & 1u) ? set : ~set;
+            }
+            const uint32_t first_slot = live ? cur[w][digit] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // every lane has read the cursors before a leader moves one
+            if (live) {
+                const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+                const uint32_t at = first_slot + rank;
+                kout[at] = key;
+                if (vin) vout[at] = val;
+                if (rank == 0) cur[w][digit] = first_slot + (uint32_t)__popcll(peers);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the next pass reads what the other waves of this workgroup have just written
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint64_t *tk = kin;
+        kin = kout;
+        kout = tk;
+        uint32_t *tv = vin;
+        vin = vout;
+        vout = tv;
+    }
+}
+
 }  // namespace pcrs
 
 using namespace pcrs;
@@ -86,6 +174,17 @@ int pcrs_sort_pairs_u64(pcrs_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t 
     if (n <= 1 || key_bits <= 0) return PCRS_OK;
     if (n >= 0xFFFFFFFFull) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "sort too long");
     if (key_bits > 64) key_bits = 64;
+    static const bool one_launch = [] {  // experiments only: PCRS_SORT_SMALL=0
+        const char *e = getenv("PCRS_SORT_SMALL");
+        return !(e && e[0] == '0');
+    }();
+    if (one_launch && n <= RS_SMALL_MAX) {
+        hipLaunchKernelGGL(radix_sort_small_kernel, dim3(1), dim3(RS_SMALL_WAVES * 64), 0, ctx->stream, keys,
+                           vals, keys_alt, vals ? vals_alt : nullptr, (uint32_t)n, key_bits);
+        PCRS_HIP_CHECK(ctx, hipGetLastError());
+        *in_alt = (((key_bits + 7) / 8) & 1) != 0;
+        return PCRS_OK;
+    }
     const uint32_t nchunks = (uint32_t)((n + RS_CHUNK - 1) / RS_CHUNK);
     const size_t entries = (size_t)256 * nchunks;
     DevBuf table, sums;

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64) void radix_scatter_kernel(const uint64_t *keys,
 // an LDS table, the table is scanned digit-major (so the passes stay stable), and the wave scatters
 // its part with the ballot ranking of radix_scatter_kernel.  Three launches a pass cost a frame of
 // a LiDAR (four sorts of 2-3 passes over 2-57 K keys) more than the sorting itself.
-constexpr uint32_t RS_SMALL_MAX = 8192;
+constexpr uint32_t RS_SMALL_MAX = 65536;   // what the kernel can take
+constexpr uint32_t RS_SMALL_DEFAULT = 16384; // up to where it beats three launches a pass
 constexpr int RS_SMALL_WAVES = 16;
 
 __global__ __launch_bounds__(RS_SMALL_WAVES * 64) void radix_sort_small_kernel(
@@ -174,11 +175,13 @@ int pcrs_sort_pairs_u64(pcrs_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t 
     if (n <= 1 || key_bits <= 0) return PCRS_OK;
     if (n >= 0xFFFFFFFFull) return pcrs_set_err(ctx, PCRS_ERR_INVALID_ARG, "sort too long");
     if (key_bits > 64) key_bits = 64;
-    static const bool one_launch = [] {  // experiments only: PCRS_SORT_SMALL=0
+    static const size_t small_max = [] {  // experiments only: PCRS_SORT_SMALL=<keys>, 0 = never
         const char *e = getenv("PCRS_SORT_SMALL");
-        return !(e && e[0] == '0');
+        if (!e) return (size_t)RS_SMALL_DEFAULT;
+        const long v = atol(e);
+        return (size_t)(v < 0 ? 0 : (v > (long)RS_SMALL_MAX ? (long)RS_SMALL_MAX : v));
     }();
-    if (one_launch && n <= RS_SMALL_MAX) {
+    if (n <= small_max) {
         hipLaunchKernelGGL(radix_sort_small_kernel, dim3(1), dim3(RS_SMALL_WAVES * 64), 0, ctx->stream, keys,
                            vals, keys_alt, vals ? vals_alt : nullptr, (uint32_t)n, key_bits);
         PCRS_HIP_CHECK(ctx, hipGetLastError());

@@ -395,7 +395,13 @@ size_t pcrs_index_len(const pcrs_index *index) { return index ? index->m : 0; }
 int pcrs_index_levels(const pcrs_index *index, uint32_t *n_finer, uint32_t *n_coarser) {
     if (!index || !n_finer || !n_coarser) return PCRS_ERR_INVALID_ARG;
     *n_finer = *n_coarser = 0;
-    for (const pcrs_index *l = index->child; l; l = l->child) ++*n_finer;
+    std::vector<const pcrs_index *> todo(index->kids.begin(), index->kids.end());
+    while (!todo.empty()) {
+        const pcrs_index *l = todo.back();
+        todo.pop_back();
+        ++*n_finer;
+        todo.insert(todo.end(), l->kids.begin(), l->kids.end());
+    }
     for (const pcrs_index *l = index->coarse; l; l = l->coarse) ++*n_coarser;
     return PCRS_OK;
 }

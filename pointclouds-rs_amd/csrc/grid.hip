@@ -537,6 +537,34 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
 // bit 31 of a retry-list entry: "not tried yet, just too crowded for one lane"
 constexpr uint32_t PCRS_HEAVY_FLAG = 0x80000000u;
 
+// Which sorted slots are queries: original index in [q_begin, q_begin + q_len) and, with boxes,
+// inside `in` but inside none of the n_ex boxes `ex` (a slab of a sharded cloud; a level of a
+// refined index without the parts its finer grids answer).
+// handed (nullable): a byte per point of the columns; a point whose byte equals `level` is a query
+// too, whatever the boxes say (a level of a refined index: what the level before it passed on).
+// no_own: only those.
+struct SlotChoice {
+    uint32_t q_begin, q_len;
+    bool boxes;
+    BoxFilter in;
+    BoxFilter ex[PCRS_MAX_KIDS];
+    int n_ex;
+    const uint8_t *handed;
+    uint8_t level;
+    bool no_own;
+};
+// The test itself, for one sorted slot.
+__device__ __forceinline__ bool slot_is_query(const SlotChoice &ch, const float4 &p) {
+    const uint32_t orig = __float_as_uint(p.w);
+    bool own = (orig - ch.q_begin) < ch.q_len && !ch.no_own;
+    if (ch.boxes) {
+        own = own && point_taken(ch.in, p.x, p.y, p.z);
+        for (int j = 0; j < ch.n_ex; ++j) own = own && !point_taken(ch.ex[j], p.x, p.y, p.z);
+    }
+    if (ch.handed) own = own || ch.handed[orig] == ch.level;
+    return own;
+}
+
 struct CellArgs {
     GridGeom g;
     const uint32_t *cell_start;
@@ -551,7 +579,10 @@ struct CellArgs {
     //   qmode 3: sorted slot qlist[p], p < *qcount (self queries of a sub-range, compacted)
     //   qmode 4: entry p of qpts (external queries sorted by grid cell: x, y, z, query index),
     //            p < *qcount
+    //   qmode 5: like 0, but only the slots that pass *choice (device memory) are queries: a level
+    //            of a refined index that answers most of its points needs no compacted list
     int qmode;
+    const SlotChoice *choice;
     const float4 *qpts;
     const float *qx, *qy, *qz;
     uint32_t nq;
@@ -718,17 +749,18 @@ void knn_cell_kernel(CellArgs a, KnnOut out) {
     if (a.zero_me && blockIdx.x == 0 && threadIdx.x < 16) a.zero_me[threadIdx.x] = 0u;
     if (a.skip && *a.skip) return;
     uint32_t total = a.nq;
-    if (a.qmode >= 2) total = *a.qcount;
+    if (a.qmode >= 2 && a.qmode != 5) total = *a.qcount;
     const GridGeom &g = a.g;
 
     for (uint32_t pos = xcd_contiguous_block(blockIdx.x, gridDim.x) * GB_THREADS + threadIdx.x;
          pos < total; pos += gridDim.x * GB_THREADS) {
         uint32_t qi;
         float qx, qy, qz;
-        if (a.qmode == 0 || a.qmode == 3) {
+        if (a.qmode == 0 || a.qmode == 3 || a.qmode == 5) {
             const float4 p = a.spts[a.qmode == 3 ? a.qlist[pos] : pos];
             const uint32_t orig = __float_as_uint(p.w);
             if (orig - a.q_begin >= a.q_len) continue;  // not a query of this call
+            if (a.qmode == 5 && !slot_is_query(*a.choice, p)) continue;
             qi = orig - a.q_begin;
             qx = p.x;
             qy = p.y;
@@ -1061,7 +1093,7 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
     if (a.zero_me && blockIdx.x == 0 && threadIdx.x < 16) a.zero_me[threadIdx.x] = 0u;
     if (a.skip && *a.skip) return;
     uint32_t total = a.nq;
-    if (a.qmode >= 2) total = *a.qcount;
+    if (a.qmode >= 2 && a.qmode != 5) total = *a.qcount;
     const GridGeom &g = a.g;
     const uint32_t keff = a.kcert;
 
@@ -1069,10 +1101,11 @@ void knn_tag_kernel(CellArgs a, KnnOut out) {
          pos < total; pos += gridDim.x * GB_THREADS) {
         uint32_t qi;
         float qx, qy, qz;
-        if (a.qmode == 0 || a.qmode == 3) {
+        if (a.qmode == 0 || a.qmode == 3 || a.qmode == 5) {
             const float4 p = a.spts[a.qmode == 3 ? a.qlist[pos] : pos];
             const uint32_t orig = __float_as_uint(p.w);
             if (orig - a.q_begin >= a.q_len) continue;  // not a query of this call
+            if (a.qmode == 5 && !slot_is_query(*a.choice, p)) continue;
             qi = orig - a.q_begin;
             qx = p.x;
             qy = p.y;
@@ -1717,20 +1750,6 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
 constexpr int OWN_PER_THREAD = 4;
 constexpr int OWN_BLOCK = GB_THREADS * OWN_PER_THREAD;
 
-// Which sorted slots are queries: original index in [q_begin, q_begin + q_len) and, with boxes,
-// inside `in` but not inside `ex` (a slab of a sharded cloud; a level of a refined index without
-// the part the next level answers).
-// handed (nullable): a byte per point of the columns; a point whose byte equals `level` is a query
-// too, whatever the boxes say (a level of a refined index: what the level before it passed on).
-// no_own: only those.
-struct SlotChoice {
-    uint32_t q_begin, q_len;
-    bool boxes;
-    BoxFilter in, ex;
-    const uint8_t *handed;
-    uint8_t level;
-    bool no_own;
-};
 __device__ __forceinline__ uint32_t owned_flags(const float4 *spts, uint32_t nvalid, uint32_t first,
                                                 const SlotChoice &ch) {
     uint32_t f = 0;
@@ -1738,12 +1757,7 @@ __device__ __forceinline__ uint32_t owned_flags(const float4 *spts, uint32_t nva
     for (int i = 0; i < OWN_PER_THREAD; ++i) {
         const uint32_t s = first + i;
         if (s < nvalid) {
-            const float4 p = spts[s];
-            bool own = (__float_as_uint(p.w) - ch.q_begin) < ch.q_len && !ch.no_own;
-            if (ch.boxes)
-                own = own && point_taken(ch.in, p.x, p.y, p.z) && !point_taken(ch.ex, p.x, p.y, p.z);
-            if (ch.handed) own = own || ch.handed[__float_as_uint(p.w)] == ch.level;
-            if (own) f |= 1u << i;
+            if (slot_is_query(ch, spts[s])) f |= 1u << i;
         }
     }
     return f;
@@ -2238,6 +2252,99 @@ __global__ __launch_bounds__(GB_THREADS) void dense_scan_kernel(const uint32_t *
     if (threadIdx.x == 0 && sshort) atomicAdd(&out->short_points, sshort);
 }
 
+// The same look at the crowded cells, kept apart by region: the grid is divided into DENSE_B^3
+// blocks of cells, and every block gets the box of its crowded cells (low sides stored reversed,
+// as above), their number and their points.  The host joins neighbouring blocks into regions.
+constexpr int DENSE_B = 16;
+constexpr int DENSE_T = 3;  // thresholds looked at in one pass: threshold, 2x, 4x
+struct DenseBlock {
+    uint32_t hi[3], lo_rev[3];
+    uint32_t cells, pad;
+    unsigned long long points;
+    unsigned long long heavy_points;  // of them, in cells whose cube holds more than heavy_cube points
+    unsigned long long visits;        // candidates their queries read: points x cube x walks
+};
+__global__ __launch_bounds__(GB_THREADS) void dense_blocks_kernel(const uint32_t *cell_start,
+                                                                  GridGeom g, uint32_t ncell,
+                                                                  uint32_t threshold,
+                                                                  uint32_t heavy_cube, DenseBlock *out) {
+    for (uint32_t c = blockIdx.x * GB_THREADS + threadIdx.x; c < ncell; c += gridDim.x * GB_THREADS) {
+        const uint32_t cnt = cell_start[c + 1] - cell_start[c];
+        if (cnt <= threshold) continue;
+        const uint32_t cx = c % (uint32_t)g.nx, cy = (c / (uint32_t)g.nx) % (uint32_t)g.ny;
+        const uint32_t cz = c / ((uint32_t)g.nx * (uint32_t)g.ny);
+        // the cell's 3 x 3 x 3 cube, as the search kernels count it: nine runs of up to three cells
+        uint32_t cube = 0;
+        {
+            const int x0 = cx ? (int)cx - 1 : 0, x1 = (int)cx + 1 < g.nx ? (int)cx + 1 : g.nx - 1;
+            for (int zz = (int)cz - 1; zz <= (int)cz + 1; ++zz) {
+                if (zz < 0 || zz >= g.nz) continue;
+                for (int yy = (int)cy - 1; yy <= (int)cy + 1; ++yy) {
+                    if (yy < 0 || yy >= g.ny) continue;
+                    const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+                    cube += cell_start[row + x1 + 1] - cell_start[row + x0];
+                }
+            }
+        }
+        const uint32_t bx = cx * DENSE_B / (uint32_t)g.nx, by = cy * DENSE_B / (uint32_t)g.ny;
+        const uint32_t bz = cz * DENSE_B / (uint32_t)g.nz;
+        for (int t = 0; t < DENSE_T; ++t) {  // out[t]: the cells above threshold << t
+            if (cnt <= (threshold << t)) break;
+            DenseBlock *b = out + (size_t)t * DENSE_B * DENSE_B * DENSE_B + (bz * DENSE_B + by) * DENSE_B + bx;
+            atomicMax(&b->hi[0], cx);
+            atomicMax(&b->hi[1], cy);
+            atomicMax(&b->hi[2], cz);
+            atomicMax(&b->lo_rev[0], (uint32_t)g.nx - 1u - cx);
+            atomicMax(&b->lo_rev[1], (uint32_t)g.ny - 1u - cy);
+            atomicMax(&b->lo_rev[2], (uint32_t)g.nz - 1u - cz);
+            atomicAdd(&b->cells, 1u);
+            atomicAdd(&b->points, (unsigned long long)cnt);
+            if (cube > heavy_cube) atomicAdd(&b->heavy_points, (unsigned long long)cnt);
+            else atomicAdd(&b->visits, (unsigned long long)cnt * cube * (cube > 1024u ? 2u : 1u));
+        }
+    }
+}
+
+// The points of a box of cells of a sorted grid as columns of their own (x, y, z and the index in
+// the cloud's columns), row by row: rows[r] = first slot of row r's run of cells, offs[r] = where
+// its points go (an exclusive scan of the run lengths, offs[nrows] = their sum).
+__global__ __launch_bounds__(GB_THREADS) void box_row_len_kernel(const uint32_t *cell_start, GridGeom g,
+                                                                 int x0, int x1, int y0, int ny, int z0,
+                                                                 uint32_t nrows, uint32_t *rows,
+                                                                 uint32_t *lens) {
+    const uint32_t r = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (r >= nrows) return;
+    const int yy = y0 + (int)(r % (uint32_t)ny), zz = z0 + (int)(r / (uint32_t)ny);
+    const uint32_t row = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx;
+    const uint32_t s0 = cell_start[row + x0];
+    rows[r] = s0;
+    lens[r] = cell_start[row + x1 + 1] - s0;
+}
+
+__global__ __launch_bounds__(64) void box_gather_kernel(const float4 *spts, const uint32_t *rows,
+                                                        const uint32_t *offs, uint32_t nrows,
+                                                        uint32_t total, float *ox, float *oy, float *oz,
+                                                        uint32_t *oidx) {
+    const uint32_t r = blockIdx.x;
+    if (r >= nrows) return;
+    const uint32_t s0 = rows[r], o0 = offs[r];
+    const uint32_t len = (r + 1 < nrows ? offs[r + 1] : total) - o0;
+    for (uint32_t t = threadIdx.x; t < len; t += 64) {
+        const float4 p = spts[s0 + t];
+        ox[o0 + t] = p.x;
+        oy[o0 + t] = p.y;
+        oz[o0 + t] = p.z;
+        oidx[o0 + t] = __float_as_uint(p.w);
+    }
+}
+
+// spts[i].w (an index into gathered columns) -> the index in the cloud's columns
+__global__ __launch_bounds__(GB_THREADS) void remap_index_kernel(float4 *spts, uint32_t n,
+                                                                 const uint32_t *index) {
+    const uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (i < n) spts[i].w = __uint_as_float(index[__float_as_uint(spts[i].w)]);
+}
+
 // Puts the points of every cell into ascending original-index order (one thread per cell; the
 // scatter's atomics leave them in arrival order).  Used where a reproducible point order matters.
 __global__ __launch_bounds__(GB_THREADS) void sort_cells_kernel(const uint32_t *cell_start,
@@ -2372,11 +2479,14 @@ double target_occupancy(uint32_t k_hint) {
 // non-empty cells, a spare word and the 64-bit sum of squared cell counts (8-byte aligned).
 static inline size_t nonempty_slot(uint32_t ncell) { return ((size_t)ncell + 2) & ~(size_t)1; }
 
-// cells per axis at most (experiments may override it: PCRS_GRID_MAXDIM)
+// Cells per axis at most (experiments may override it: PCRS_GRID_MAXDIM).  The positions are f32:
+// the certification margins allow 2e-6 of the extent for rounding, 1 % of a cell at 4096 cells per
+// axis.  (A limit of 1024 made the cells of a flat scene of a hundred million points -- a survey
+// flight, 2 km x 2 km -- four times too wide: 454 ms against 208 ms for the search.)
 static const double kMaxDim = [] {
     const char *e = getenv("PCRS_GRID_MAXDIM");
     const double v = e ? atof(e) : 0.0;
-    return v >= 16.0 && v <= 65536.0 ? v : 1024.0;
+    return v >= 16.0 && v <= 65536.0 ? v : 4096.0;
 }();
 
 // Geometry for a requested cell edge: dims per axis (capped), cell enlarged until the cell count
@@ -2487,7 +2597,12 @@ static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, con
 
 int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     pcrs_ctx *ctx = ix->ctx;
-    const uint32_t m = (uint32_t)ix->m;
+    // the points to sort: the cloud's columns, or a gathered part of them (see pcrs_index::src_cols)
+    const bool from_src = ix->src_n > 0;
+    const uint32_t m = (uint32_t)(from_src ? ix->src_n : ix->m);
+    const float *bx = from_src ? ix->src_cols.as<float>() : ix->x;
+    const float *by = from_src ? ix->src_cols.as<float>() + ix->src_n : ix->y;
+    const float *bz = from_src ? ix->src_cols.as<float>() + 2 * ix->src_n : ix->z;
     ix->algo = PCRS_ALGO_BRUTE;
     if (m == 0) return PCRS_OK;
 
@@ -2511,8 +2626,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         }
         nvalid = ix->bounds_n_upper;
     } else {
-        hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
-                           ix->z, m, box, hp);
+        hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, bx, by, bz, m, box, hp);
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         for (unsigned b = 0; b < nb; ++b) {
             const BBoxPartial &p = hp[b];
@@ -2624,7 +2738,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             }
             if (!ix->counters.p) PCRS_HIP_CHECK(ctx, ix->counters.alloc(ctx, 32 * sizeof(uint32_t)));
             ix->counter_phase = 0;
-            PCRS_TRY(run_two_level_sort(ctx, ix->x, ix->y, ix->z, m, sp, table.as<uint32_t>(),
+            PCRS_TRY(run_two_level_sort(ctx, bx, by, bz, m, sp, table.as<uint32_t>(),
                                         table_sums.as<uint32_t>(), tmp.as<float4>(),
                                         sorted.as<float4>(), counts.as<uint32_t>(), d_nonempty,
                                         sorted3.as<float>(), ix->counters.as<uint32_t>()));
@@ -2632,8 +2746,8 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             if (!cell_id.p) PCRS_HIP_CHECK(ctx, cell_id.alloc(ctx, (size_t)m * sizeof(uint32_t)));
             PCRS_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, ((size_t)ncell + 6) * sizeof(uint32_t),
                                                ctx->stream));
-            hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x,
-                               ix->y, ix->z, m, g, box, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
+            hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, bx,
+                               by, bz, m, g, box, cell_id.as<uint32_t>(), counts.as<uint32_t>(),
                                d_nonempty);
         }
         sorted_done = two_level;
@@ -2764,8 +2878,8 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(fill.p, counts.p, (size_t)ncell * sizeof(uint32_t),
                                            hipMemcpyDeviceToDevice, ctx->stream));
         PCRS_HIP_CHECK(ctx, ix->spts.alloc(ctx, nvalid * sizeof(float4)));
-        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, ix->x, ix->y,
-                           ix->z, m, cell_id.as<uint32_t>(), fill.as<uint32_t>(),
+        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(GB_THREADS), 0, ctx->stream, bx, by,
+                           bz, m, cell_id.as<uint32_t>(), fill.as<uint32_t>(),
                            ix->spts.as<float4>());
         PCRS_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -2784,6 +2898,15 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         ctx->grid_hint.dim = dim;
         ctx->grid_hint.n = nvalid;
         ctx->grid_hint.k_hint = k_hint;
+    }
+    if (from_src) {  // the sort numbered the gathered points: back to the cloud's own indices
+        hipLaunchKernelGGL(remap_index_kernel, dim3((unsigned)((nvalid + GB_THREADS - 1) / GB_THREADS)),
+                           dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(), (uint32_t)nvalid,
+                           ix->src_index.as<uint32_t>());
+        PCRS_HIP_CHECK(ctx, hipGetLastError());
+        ix->src_cols.release();
+        ix->src_index.release();
+        ix->src_n = 0;
     }
     ix->algo = PCRS_ALGO_GRID;
     return PCRS_OK;
@@ -2906,7 +3029,11 @@ static int grid_coarsen(pcrs_index *ix, uint32_t k_hint, unsigned long long shor
     pcrs_ctx *ctx = ix->ctx;
     const GridGeom &g = ix->g;
     if (!coarse_enabled() || depth >= kCoarseMaxDepth) return PCRS_OK;
-    if (short_points < std::max<unsigned long long>(8192, ix->nvalid / 64)) return PCRS_OK;
+    static const unsigned long long coarse_min = [] {  // experiments only: PCRS_GRID_COARSE_MIN=<points>
+        const char *e = getenv("PCRS_GRID_COARSE_MIN");
+        return e ? (unsigned long long)atoll(e) : 8192ull;
+    }();
+    if (short_points < std::max<unsigned long long>(coarse_min, ix->nvalid / 64)) return PCRS_OK;
     if (std::max(g.nx, std::max(g.ny, g.nz)) < 12) return PCRS_OK;  // a handful of cells already
     pcrs_index *c = new (std::nothrow) pcrs_index();
     if (!c) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
@@ -2968,53 +3095,227 @@ int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth) {
     const size_t enough = std::max<size_t>(16384, ix->nvalid / 20);
     if (ds.cells == 0 || ds.points < enough) return PCRS_OK;
     const int n[3] = {g.nx, g.ny, g.nz};
-    int lo_c[3], hi_c[3];
-    double vol = 1.0, whole = 1.0;
-    for (int a = 0; a < 3; ++a) {
-        hi_c[a] = (int)ds.hi[a];
-        lo_c[a] = n[a] - 1 - (int)ds.lo_rev[a];
-        vol *= (double)(hi_c[a] - lo_c[a] + 1);
-        whole *= (double)n[a];
+    struct Region {
+        int lo[3], hi[3];
+        unsigned long long points, heavy_points, visits;
+        uint32_t cells;
+    };
+    std::vector<Region> regions;
+    double whole = 1.0;
+    for (int a = 0; a < 3; ++a) whole *= (double)n[a];
+    auto volume = [](const Region &r) {
+        double v = 1.0;
+        for (int a = 0; a < 3; ++a) v *= (double)(r.hi[a] - r.lo[a] + 1);
+        return v;
+    };
+    {
+        Region one{};
+        for (int a = 0; a < 3; ++a) {
+            one.hi[a] = (int)ds.hi[a];
+            one.lo[a] = n[a] - 1 - (int)ds.lo_rev[a];
+        }
+        one.points = ds.points;
+        one.cells = ds.cells;
+        if (volume(one) <= 0.3 * whole) regions.push_back(one);
     }
-    // crowded cells all over the grid: one box around them is the grid again
-    if (vol > 0.6 * whole) return PCRS_OK;
+    if (regions.empty()) {
+        // Crowded cells all over the grid (the roofs and trees of a survey, the cars of a street):
+        // one box around them is the grid again.  They are looked at block by block, neighbouring
+        // blocks with crowded cells are joined into regions, and every region that is worth a
+        // grid of its own gets one.
+        // Where the lowest bar makes one region of everything (flat patches of a terrain are
+        // crowded by it too) a bar two or four times as high is tried: all three are counted in
+        // the one pass.
+        constexpr size_t nblk = (size_t)DENSE_B * DENSE_B * DENSE_B;
+        DevBuf d;
+        PCRS_HIP_CHECK(ctx, d.alloc(ctx, DENSE_T * nblk * sizeof(DenseBlock)));
+        PCRS_HIP_CHECK(ctx, hipMemsetAsync(d.p, 0, DENSE_T * nblk * sizeof(DenseBlock), ctx->stream));
+        hipLaunchKernelGGL(dense_blocks_kernel, dim3(grid_for(ctx, ix->ncell, GB_THREADS)), dim3(GB_THREADS), 0,
+                           ctx->stream, ix->cell_start.as<uint32_t>(), g, ix->ncell, threshold, 8192u,
+                           d.as<DenseBlock>());
+        std::vector<DenseBlock> hall(DENSE_T * nblk);
+        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(hall.data(), d.p, DENSE_T * nblk * sizeof(DenseBlock),
+                                           hipMemcpyDeviceToHost, ctx->stream));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int t = 0; t < DENSE_T && regions.empty(); ++t) {
+            const DenseBlock *hb = hall.data() + (size_t)t * nblk;
+            std::vector<int> label(nblk, -1);
+            std::vector<size_t> stack;
+            for (size_t b0 = 0; b0 < nblk; ++b0) {
+                if (!hb[b0].cells || label[b0] >= 0) continue;
+                Region r{};
+                for (int a = 0; a < 3; ++a) {
+                    r.lo[a] = n[a];
+                    r.hi[a] = -1;
+                }
+                label[b0] = (int)regions.size();
+                stack.assign(1, b0);
+                while (!stack.empty()) {
+                    const size_t b = stack.back();
+                    stack.pop_back();
+                    const DenseBlock &k = hb[b];
+                    for (int a = 0; a < 3; ++a) {
+                        r.lo[a] = std::min(r.lo[a], n[a] - 1 - (int)k.lo_rev[a]);
+                        r.hi[a] = std::max(r.hi[a], (int)k.hi[a]);
+                    }
+                    r.points += k.points;
+                    r.heavy_points += k.heavy_points;
+                    r.visits += k.visits;
+                    r.cells += k.cells;
+                    const int bx = (int)(b % DENSE_B), by = (int)((b / DENSE_B) % DENSE_B),
+                              bz = (int)(b / (DENSE_B * DENSE_B));
+                    for (int dz = -1; dz <= 1; ++dz)
+                        for (int dy = -1; dy <= 1; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                const int x2 = bx + dx, y2 = by + dy, z2 = bz + dz;
+                                if (x2 < 0 || y2 < 0 || z2 < 0 || x2 >= DENSE_B || y2 >= DENSE_B || z2 >= DENSE_B)
+                                    continue;
+                                const size_t nb2 = ((size_t)z2 * DENSE_B + y2) * DENSE_B + x2;
+                                if (hb[nb2].cells && label[nb2] < 0) {
+                                    label[nb2] = label[b0];
+                                    stack.push_back(nb2);
+                                }
+                            }
+                }
+                regions.push_back(r);
+            }
+            // the boxes of two regions may still overlap (an L around a corner): such regions are one
+            for (bool merged = true; merged;) {
+                merged = false;
+                for (size_t i = 0; i < regions.size() && !merged; ++i)
+                    for (size_t j = i + 1; j < regions.size() && !merged; ++j) {
+                        bool apart = false;
+                        for (int a = 0; a < 3; ++a)
+                            apart = apart || regions[i].hi[a] + 1 < regions[j].lo[a] - 1 ||
+                                    regions[j].hi[a] + 1 < regions[i].lo[a] - 1;
+                        if (apart) continue;
+                        for (int a = 0; a < 3; ++a) {
+                            regions[i].lo[a] = std::min(regions[i].lo[a], regions[j].lo[a]);
+                            regions[i].hi[a] = std::max(regions[i].hi[a], regions[j].hi[a]);
+                        }
+                        regions[i].points += regions[j].points;
+                        regions[i].heavy_points += regions[j].heavy_points;
+                        regions[i].visits += regions[j].visits;
+                        regions[i].cells += regions[j].cells;
+                        regions.erase(regions.begin() + (long)j);
+                        merged = true;
+                    }
+            }
+            // A grid of its own costs a region about half a millisecond (a gather, a sort or two,
+            // five read-backs).  It pays where the region's cubes are too crowded for a lane (more
+            // than 8192 points: every query there takes the wave-per-query kernel, some 30 ns
+            // each), or where the candidates the lanes would read here (1.6 ps each: 0.3 ns for
+            // the 190 of an evenly filled cube; cubes of more than 1024 are walked twice) cost
+            // three quarters of a millisecond more than in a grid of the region's own.  The
+            // largest first; together a small part of the grid.
+            static const double region_ms = [] {  // experiments only: PCRS_GRID_REGION_MS=<ms>
+                const char *e = getenv("PCRS_GRID_REGION_MS");
+                return e ? atof(e) : 0.75;
+            }();
+            static const unsigned long long region_heavy = [] {  // experiments only
+                const char *e = getenv("PCRS_GRID_REGION_HEAVY");
+                return e ? (unsigned long long)atoll(e) : 8192ull;
+            }();
+            for (size_t i = 0; i < regions.size();) {
+                const Region &q = regions[i];
+                const double lane_ms = (double)q.visits * 1.6e-9 - (double)q.points * 0.3e-6;
+                const bool pays = q.points >= 16384 && (q.heavy_points >= region_heavy || lane_ms >= region_ms);
+                if (pays) ++i; else regions.erase(regions.begin() + (long)i);
+            }
+            std::sort(regions.begin(), regions.end(),
+                      [](const Region &a, const Region &b) { return a.points > b.points; });
+            while (regions.size() > (size_t)PCRS_MAX_KIDS) regions.pop_back();
+            unsigned long long sum = 0;
+            double vsum = 0.0;
+            for (const Region &r : regions) {
+                sum += r.points;
+                vsum += volume(r);
+            }
+            if (regions.empty() || vsum > 0.3 * whole) regions.clear();
+            (void)sum;
+        }
+        if (regions.empty()) return PCRS_OK;
+    }
     const double o[3] = {g.ox, g.oy, g.oz};
-    BoxFilter qbox = pcrs_no_box(), pbox = ix->box;
-    for (int a = 0; a < 3; ++a) {
-        // a side on the grid's own end has nothing of this grid behind it
-        if (lo_c[a] > 0) {
-            qbox.lo[a] = (float)(o[a] + (double)lo_c[a] * (double)g.cell);
-            pbox.lo[a] = (float)(o[a] + (double)(lo_c[a] - 1) * (double)g.cell);
+    int rc_all = PCRS_OK;
+    for (const Region &r : regions) {
+        BoxFilter qbox = pcrs_no_box(), pbox = ix->box;
+        for (int a = 0; a < 3; ++a) {
+            // a side on the grid's own end has nothing of this grid behind it
+            if (r.lo[a] > 0) {
+                qbox.lo[a] = (float)(o[a] + (double)r.lo[a] * (double)g.cell);
+                pbox.lo[a] = (float)(o[a] + (double)(r.lo[a] - 1) * (double)g.cell);
+            }
+            if (r.hi[a] < n[a] - 1) {
+                qbox.hi[a] = (float)(o[a] + (double)(r.hi[a] + 1) * (double)g.cell);
+                pbox.hi[a] = (float)(o[a] + (double)(r.hi[a] + 2) * (double)g.cell);
+            }
         }
-        if (hi_c[a] < n[a] - 1) {
-            qbox.hi[a] = (float)(o[a] + (double)(hi_c[a] + 1) * (double)g.cell);
-            pbox.hi[a] = (float)(o[a] + (double)(hi_c[a] + 2) * (double)g.cell);
+        pcrs_index *child = new (std::nothrow) pcrs_index();
+        if (!child) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
+        child->ctx = ctx;
+        child->x = ix->x;
+        child->y = ix->y;
+        child->z = ix->z;
+        child->m = ix->m;
+        child->k_hint = k_hint;
+        child->box = pbox;
+        // (only where the region is a small part of the cloud: gathering costs a read-back of its
+        // own, and three passes over a cloud of a million points cost less than that)
+        if ((double)r.points * 8.0 < (double)ix->m) {
+            // the child's points are gathered from this grid's cells around the box (two cells
+            // more than the box on every side: the box's own margin of one, and one for points
+            // whose cell the rounding of the cell assignment put next door); the child's sort then
+            // reads those instead of passing over the whole cloud three times an attempt
+            const int x0 = std::max(r.lo[0] - 2, 0), x1 = std::min(r.hi[0] + 2, n[0] - 1);
+            const int y0 = std::max(r.lo[1] - 2, 0), y1 = std::min(r.hi[1] + 2, n[1] - 1);
+            const int z0 = std::max(r.lo[2] - 2, 0), z1 = std::min(r.hi[2] + 2, n[2] - 1);
+            const uint32_t nrows = (uint32_t)(y1 - y0 + 1) * (uint32_t)(z1 - z0 + 1);
+            DevBuf rows, lens, sums;
+            PCRS_HIP_CHECK(ctx, rows.alloc(ctx, ((size_t)nrows + 2) * sizeof(uint32_t)));
+            PCRS_HIP_CHECK(ctx, lens.alloc(ctx, ((size_t)nrows + 2) * sizeof(uint32_t)));
+            PCRS_HIP_CHECK(ctx, sums.alloc(ctx, ((size_t)nrows / 1024 + 4) * sizeof(uint32_t)));
+            hipLaunchKernelGGL(box_row_len_kernel, dim3((nrows + GB_THREADS - 1) / GB_THREADS), dim3(GB_THREADS), 0,
+                               ctx->stream, ix->cell_start.as<uint32_t>(), g, x0, x1, y0, y1 - y0 + 1, z0, nrows,
+                               rows.as<uint32_t>(), lens.as<uint32_t>());
+            PCRS_TRY(pcrs_launch_scan_u32(ctx, lens.as<uint32_t>(), nrows, sums.as<uint32_t>(),
+                                          lens.as<uint32_t>() + nrows));
+            void *pin = nullptr;
+            PCRS_TRY(pcrs_ctx_pinned(ctx, 64, &pin));
+            PCRS_TRY(pcrs_launch_publish(ctx, lens.as<uint32_t>() + nrows, pin, sizeof(uint32_t)));
+            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t total = *reinterpret_cast<const uint32_t *>(pin);
+            if (total < 16384) {
+                delete child;
+                continue;
+            }
+            PCRS_HIP_CHECK(ctx, child->src_cols.alloc(ctx, (size_t)total * 3 * sizeof(float)));
+            PCRS_HIP_CHECK(ctx, child->src_index.alloc(ctx, (size_t)total * sizeof(uint32_t)));
+            child->src_n = total;
+            hipLaunchKernelGGL(box_gather_kernel, dim3(nrows), dim3(64), 0, ctx->stream, ix->spts.as<float4>(),
+                               rows.as<uint32_t>(), lens.as<uint32_t>(), nrows, total,
+                               child->src_cols.as<float>(), child->src_cols.as<float>() + total,
+                               child->src_cols.as<float>() + 2 * (size_t)total, child->src_index.as<uint32_t>());
+            PCRS_HIP_CHECK(ctx, hipGetLastError());
         }
+        const int rc = pcrs_grid_build(child, k_hint);
+        if (debug)
+            fprintf(stderr, "pcrs grid level %d: %u crowded cells (> %u points) with %llu points in a box of "
+                            "%d x %d x %d cells; finer grid over %zu points, cell %.5g (this level %.5g)\n",
+                    depth + 1, r.cells, threshold, r.points, r.hi[0] - r.lo[0] + 1, r.hi[1] - r.lo[1] + 1,
+                    r.hi[2] - r.lo[2] + 1, child->nvalid, (double)child->g.cell, (double)g.cell);
+        // a level must be a real step: enough points, markedly smaller cells
+        if (rc != PCRS_OK || child->algo != PCRS_ALGO_GRID || child->nvalid < 16384 ||
+            !(child->g.cell < 0.8f * g.cell)) {
+            delete child;
+            if (rc != PCRS_OK) rc_all = rc;
+            continue;
+        }
+        ix->kids.push_back(child);
+        ix->kid_qbox.push_back(qbox);
+        PCRS_TRY(pcrs_grid_refine(child, k_hint, depth + 1));
     }
-    pcrs_index *child = new (std::nothrow) pcrs_index();
-    if (!child) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
-    child->ctx = ctx;
-    child->x = ix->x;
-    child->y = ix->y;
-    child->z = ix->z;
-    child->m = ix->m;
-    child->k_hint = k_hint;
-    child->box = pbox;
-    int rc = pcrs_grid_build(child, k_hint);
-    if (debug)
-        fprintf(stderr, "pcrs grid level %d: %u crowded cells (> %u points) with %llu points in a box of "
-                        "%d x %d x %d cells; finer grid over %zu points, cell %.5g (this level %.5g)\n",
-                depth + 1, ds.cells, threshold, ds.points, hi_c[0] - lo_c[0] + 1, hi_c[1] - lo_c[1] + 1,
-                hi_c[2] - lo_c[2] + 1, child->nvalid, (double)child->g.cell, (double)g.cell);
-    // a level must be a real step: enough points, markedly smaller cells
-    if (rc != PCRS_OK || child->algo != PCRS_ALGO_GRID || child->nvalid < 16384 ||
-        !(child->g.cell < 0.8f * g.cell)) {
-        delete child;
-        return rc;
-    }
-    ix->child = child;
-    ix->child_qbox = qbox;
-    return pcrs_grid_refine(child, k_hint, depth + 1);
+    return rc_all;
 }
 
 int pcrs_grid_sorted_columns(pcrs_index *ix, float *ox, float *oy, float *oz, uint32_t *perm) {
@@ -3157,7 +3458,7 @@ int pcrs_launch_normals_from_cov(pcrs_ctx *ctx, size_t nq, const float *cov, con
 
 pcrs_index::~pcrs_index() {
     delete whole;
-    delete child;
+    for (pcrs_index *k : kids) delete k;
     delete coarse;
 }
 
@@ -3283,7 +3584,7 @@ int pcrs_grid_select_box(pcrs_index *ix, const BoxFilter &qbox, size_t *count) {
     ch.q_len = 0xFFFFFFFFu;
     ch.boxes = true;
     ch.in = qbox;
-    for (int a = 0; a < 3; ++a) ch.ex.lo[a] = ch.ex.hi[a] = 0.0f;  // an empty box: excludes nothing
+    ch.n_ex = 0;
     uint32_t *d_count = ix->sel_list.as<uint32_t>() + ix->nvalid;
     PCRS_TRY(choose_slots(ix, ch, ix->sel_list.as<uint32_t>(), d_count));
     void *pin = nullptr;
@@ -3319,42 +3620,60 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     pcrs_ctx *ctx = top->ctx;
     KnnOut out = out_in;
     const uint32_t m = (uint32_t)top->m;
-    // the order the levels run in: the finer ones finest first, the index itself, the coarser ones
+    // the order the grids run in: every grid after the finer ones under it (finest first), the
+    // index itself after all of them, the coarser ones last
     struct Level {
         pcrs_index *ix;
-        bool own;          // has queries of its own (a coarser level only takes what it is handed)
-        BoxFilter in, ex;  // its queries: inside `in`, outside `ex`
-        bool pass_sparse;  // a coarser level follows: sparse failures skip this level's wave kernel
+        bool own;            // has queries of its own (a coarser level only takes what it is handed)
+        BoxFilter in;        // its queries: inside `in` ...
+        std::vector<BoxFilter> ex;  // ... and outside the boxes its finer grids answer
+        bool pass_sparse;    // sparse failures skip this level's wave kernel for the next grid's lanes
+        int next;            // where it hands on to (position in the order), -1: nowhere
     };
     std::vector<Level> order;
     {
-        std::vector<pcrs_index *> fine;
-        for (pcrs_index *l = top; l; l = l->child) fine.push_back(l);
-        for (int li = (int)fine.size() - 1; li >= 0; --li) {
-            Level v{};
-            v.ix = fine[li];
-            v.own = true;
-            v.in = li > 0 ? fine[li - 1]->child_qbox : pcrs_no_box();
-            if (fine[li]->child) {
-                v.ex = fine[li]->child_qbox;
-            } else {
-                for (int a3 = 0; a3 < 3; ++a3) v.ex.lo[a3] = v.ex.hi[a3] = 0.0f;  // excludes nothing
+        struct Visit {
+            pcrs_index *ix;
+            BoxFilter in;
+            size_t kid;  // next of its kids to go down into
+            std::vector<int> kid_pos;
+        };
+        std::vector<Visit> stack;
+        stack.push_back(Visit{top, pcrs_no_box(), 0, {}});
+        while (!stack.empty()) {
+            Visit &v = stack.back();
+            if (v.kid < v.ix->kids.size()) {
+                const size_t j = v.kid++;
+                stack.push_back(Visit{v.ix->kids[j], v.ix->kid_qbox[j], 0, {}});
+                continue;
             }
-            v.pass_sparse = li > 0 || top->coarse != nullptr;
-            order.push_back(v);
+            Level l{};
+            l.ix = v.ix;
+            l.own = true;
+            l.in = v.in;
+            l.ex = v.ix->kid_qbox;
+            l.pass_sparse = true;
+            l.next = -1;
+            const int me = (int)order.size();
+            for (int kp : v.kid_pos) order[(size_t)kp].next = me;
+            order.push_back(l);
+            stack.pop_back();
+            if (!stack.empty()) stack.back().kid_pos.push_back(me);
         }
         for (pcrs_index *c = top->coarse; c; c = c->coarse) {
             Level v{};
             v.ix = c;
             v.own = false;
-            v.pass_sparse = c->coarse != nullptr;
+            v.pass_sparse = true;
+            v.next = -1;
+            order.back().next = (int)order.size();
             order.push_back(v);
         }
         // a sparse spot of one level is only handed to the next when that one is the next size up
         // (a millimetre blob in a scene of metres has levels a thousand times apart: the rim of
         // the blob, sparse by the blob's measure, would meet the whole blob in one cell there)
-        for (size_t i = 0; i + 1 < order.size(); ++i)
-            if (order[i + 1].ix->g.cell > 4.5f * order[i].ix->g.cell) order[i].pass_sparse = false;
+        for (Level &l : order)
+            if (l.next < 0 || order[(size_t)l.next].ix->g.cell > 4.5f * l.ix->g.cell) l.pass_sparse = false;
     }
     const bool collect = out.idx || out.dist || out.count || out.nx;
     const uint32_t keff = kneed;  // every level holds far more points than a register list
@@ -3378,11 +3697,35 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     if (top->hand_flags.bytes < (size_t)m + 64) PCRS_HIP_CHECK(ctx, top->hand_flags.alloc(ctx, (size_t)m + 64));
     uint8_t *hand = top->hand_flags.as<uint8_t>();
     if (order.size() > 1) PCRS_HIP_CHECK(ctx, hipMemsetAsync(hand, 0, m, ctx->stream));
+    std::vector<bool> is_target(order.size(), false);  // some level hands on to it
+    for (const Level &l : order)
+        if (l.next >= 0) is_target[(size_t)l.next] = true;
+    std::vector<SlotChoice> choices(order.size());
+    for (size_t li = 0; li < order.size(); ++li) {
+        const Level &lv = order[li];
+        SlotChoice ch{};
+        ch.q_begin = 0;
+        ch.q_len = m;
+        ch.boxes = true;
+        ch.in = lv.in;
+        ch.n_ex = (int)std::min<size_t>(lv.ex.size(), (size_t)PCRS_MAX_KIDS);
+        for (int j = 0; j < ch.n_ex; ++j) ch.ex[j] = lv.ex[(size_t)j];
+        ch.no_own = !lv.own;
+        ch.handed = is_target[li] ? hand : nullptr;
+        ch.level = (uint8_t)li;
+        choices[li] = ch;
+    }
+    if (!top->level_choices.p) {  // the levels of an index never change: uploaded once
+        PCRS_HIP_CHECK(ctx, top->level_choices.alloc(ctx, choices.size() * sizeof(SlotChoice)));
+        PCRS_HIP_CHECK(ctx, hipMemcpyAsync(top->level_choices.p, choices.data(), choices.size() * sizeof(SlotChoice),
+                                           hipMemcpyHostToDevice, ctx->stream));
+        PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const uint32_t *esc_list = nullptr, *esc_count = nullptr;  // what the last level left
     for (size_t li = 0; li < order.size(); ++li) {
         const Level &lv = order[li];
         pcrs_index *ix = lv.ix;
-        const bool last_level = li + 1 == order.size();
+        const bool last_level = lv.next < 0;
         const size_t list_elems = (size_t)m + 64;
         const size_t need = (5 * list_elems + 64) * sizeof(uint32_t);
         if (ix->fail_lists.bytes < need) PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
@@ -3405,19 +3748,12 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
                                (uint32_t)ix->nvalid, ix->spts3.as<float>());
         }
         // the level's queries: its own (inside its query box, outside the next finer level's)
-        // and what the level before it marked for it
-        {
-            SlotChoice ch{};
-            ch.q_begin = 0;
-            ch.q_len = m;
-            ch.boxes = true;
-            ch.in = lv.in;
-            ch.ex = lv.ex;
-            ch.no_own = !lv.own;
-            ch.handed = li > 0 ? hand : nullptr;
-            ch.level = (uint8_t)li;
-            PCRS_TRY(choose_slots(ix, ch, listS, &counters[4]));
-        }
+        // and what the level before it marked for it.  A level with queries of its own answers
+        // most of its points: its lanes go over all its slots and test each (three launches over
+        // the level's points less, and no list to read); one that only takes what it is handed
+        // gets a compacted list.
+        const bool filtered = lv.own;
+        if (!filtered) PCRS_TRY(choose_slots(ix, choices[li], listS, &counters[4]));
 
         CellArgs a{};
         a.g = ix->g;
@@ -3442,7 +3778,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         // a cube with fewer than three lists' worth of points that certifies nothing: a sparse spot
         a.sparse_below = (lv.pass_sparse && !last_level) ? 3u * keff : 0u;
         a.hand_flags = last_level ? nullptr : hand;
-        a.hand_level = (uint8_t)(li + 1);
+        a.hand_level = (uint8_t)(lv.next < 0 ? 0 : lv.next);
         a.wave_radii[0] = 1;
         a.wave_radii[1] = 2;
         a.wave_radii[2] = 4;
@@ -3459,9 +3795,15 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         const unsigned lane_blocks = std::min((unsigned)((ix->nvalid + GB_THREADS - 1) / GB_THREADS),
                                               (unsigned)ctx->num_cus * 64u);
         // stage 1 over the level's queries
-        a.qmode = 3;
-        a.qlist = listS;
-        a.qcount = &counters[4];
+        if (filtered) {
+            a.qmode = 5;
+            a.nq = (uint32_t)ix->nvalid;
+            a.choice = top->level_choices.as<SlotChoice>() + li;
+        } else {
+            a.qmode = 3;
+            a.qlist = listS;
+            a.qcount = &counters[4];
+        }
         pcrs_timing_begin(ctx);
         launch_lane_kernel(ctx, a, out, kb, collect,
                            lv.own ? lane_blocks : std::min(lane_blocks, (unsigned)ctx->num_cus * 16u));
@@ -3547,7 +3889,7 @@ int pcrs_launch_knn_grid(pcrs_index *ix, const KnnQuery &q, const KnnOut &out_in
     }
     const bool nn_only = out.nn_idx && !out.idx && !out.dist && !out.count && !out.mean && !out.nx;
     const uint32_t nq = (uint32_t)q.nq;
-    if ((ix->child || ix->coarse) && q.self && q.out_offset == 0 && q.nq == ix->m && !nn_only && !q.only_list &&
+    if ((!ix->kids.empty() || ix->coarse) && q.self && q.out_offset == 0 && q.nq == ix->m && !nn_only && !q.only_list &&
         !q.xform && keff == kneed)
         return launch_knn_levels(ix, q, out_in, kneed);
     // A pending increment of the queries (KnnQuery::xform) is applied by the 1-NN kernel as it

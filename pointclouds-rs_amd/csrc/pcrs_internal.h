@@ -165,6 +165,8 @@ inline BoxFilter pcrs_no_box() {
     return b;
 }
 
+constexpr int PCRS_MAX_KIDS = 16;  // finer grids directly under one grid
+
 struct pcrs_index {
     ~pcrs_index();
     pcrs_ctx *ctx = nullptr;
@@ -202,13 +204,18 @@ struct pcrs_index {
     // valid until the next search on this index
     const uint32_t *left_list = nullptr;
     const uint32_t *left_count = nullptr;
-    // A finer grid over the box in which this grid's cells are crowded (a scan that is dense near
-    // the sensor, a blob in a sparse scene), itself refined where it is crowded in turn: a search
-    // of the cloud's own points answers every point at the finest level whose query box holds
-    // it.  child_qbox: the part of space whose points the child answers; the child indexes a
-    // margin of one of this grid's cells more.
-    pcrs_index *child = nullptr;
-    BoxFilter child_qbox = pcrs_no_box();
+    // Finer grids over the boxes in which this grid's cells are crowded (a scan that is dense near
+    // the sensor, a blob in a sparse scene, the roofs and trees of an aerial survey), each refined
+    // in turn where it is crowded: a search of the cloud's own points answers every point at the
+    // finest grid whose query box holds it.  kid_qbox: the part of space a kid answers; the kid
+    // indexes a margin of one of this grid's cells more.
+    // A finer grid is sorted from a gathered copy of the parent's points around its box (columns
+    // of src_n points and their indices in the cloud's columns) instead of from passes over the
+    // whole cloud; only the build reads them.
+    DevBuf src_cols, src_index;
+    size_t src_n = 0;
+    std::vector<pcrs_index *> kids;   // owned
+    std::vector<BoxFilter> kid_qbox;  // the part of space each of them answers (disjoint boxes)
     // A coarser grid over the same points (cells three times as wide, itself with a coarser one
     // where that is still too fine) for the sparse parts of a cloud of very uneven density: what
     // this grid's lanes cannot certify because the query's cube held hardly any points goes to the
@@ -217,6 +224,7 @@ struct pcrs_index {
     // a byte per point of the columns, for a search over the chain of grids: the level a query
     // that one level could not answer is meant for next
     DevBuf hand_flags;
+    DevBuf level_choices;  // the query test of every level (grid.hip: SlotChoice), in the order they run
     double aim = 0.0;  // points per occupied cell the build aimed at
     // of the accepted sort, when it read them back: mean points per occupied cell, and the
     // fullness of the cell the average point sits in (sum of squared counts / points - 1)

@@ -121,3 +121,63 @@ def blob_in_box(n_blob, n_background, seed=0, sigma=1e-3, centre=3.0, half=100.0
     p = np.concatenate([c, bg])
     p = p[rng.permutation(len(p))]
     return tuple(np.ascontiguousarray(p[:, i]) for i in range(3))
+
+
+def _normal(seed, n, sigma, stream):
+    """Normal deviates (Box-Muller over two SplitMix64 streams), float32."""
+    u1 = (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    u2 = (splitmix64(seed, n, stream + 1) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return (sigma * np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)).astype(F)
+
+
+def aerial_scene(scale=1.0, seed=42, with_parts=False):
+    """The scene of examples/python/aerial_lidar.py:26-137: a 500 m x 500 m survey area with an
+    undulating terrain surface (2 M points x scale, 5 cm noise), five flat-roofed buildings (50 K
+    points x scale each: 70 % roof, 30 % on the four walls) and eight trees (20 K points x scale
+    each: 80 % on a hemispherical canopy 4 m above the ground, 20 % along the trunk).  About
+    2.41 M points at scale 1; points come part by part, as in the reference's scene.
+    with_parts: also returns [(name, begin, end)] of the parts ("terrain", "roof", "wall",
+    "canopy", "trunk").  The walls are exact planes x = const or y = const."""
+    xs, ys, zs, parts = [], [], [], []
+
+    def add(x, y, z, name):
+        begin = sum(len(a) for a in xs)
+        xs.append(np.asarray(x, dtype=F))
+        ys.append(np.asarray(y, dtype=F))
+        zs.append(np.asarray(z, dtype=F))
+        parts.append((name, begin, begin + len(xs[-1])))
+
+    st = 0
+    n = int(2_000_000 * scale)
+    tx, ty = uniform(seed, n, 0.0, 500.0, st), uniform(seed, n, 0.0, 500.0, st + 1)
+    tz = (2.0 * np.sin(tx.astype(np.float64) * 0.02) * np.cos(ty.astype(np.float64) * 0.015)).astype(F)
+    add(tx, ty, tz + _normal(seed, n, 0.05, st + 2), "terrain")
+    st += 4
+    buildings = ((100, 120, 30, 20, 12), (250, 300, 40, 40, 18), (350, 100, 25, 25, 8),
+                 (400, 400, 50, 30, 15), (150, 350, 20, 20, 10))
+    per = int(50_000 * scale)
+    for cx, cy, w, d, h in buildings:
+        nr = int(per * 0.7)
+        add(uniform(seed, nr, cx - w / 2, cx + w / 2, st), uniform(seed, nr, cy - d / 2, cy + d / 2, st + 1),
+            F(h) + _normal(seed, nr, 0.02, st + 2), "roof")
+        nw = per - nr
+        side = (splitmix64(seed, nw, st + 4) >> np.uint64(62)).astype(np.int64)  # 0..3
+        along_x = uniform(seed, nw, cx - w / 2, cx + w / 2, st + 5)
+        along_y = uniform(seed, nw, cy - d / 2, cy + d / 2, st + 6)
+        wx = np.where(side < 2, along_x, np.where(side == 2, F(cx + w / 2), F(cx - w / 2)))
+        wy = np.where(side == 0, F(cy + d / 2), np.where(side == 1, F(cy - d / 2), along_y))
+        add(wx, wy, uniform(seed, nw, 0.0, h, st + 7), "wall")
+        st += 8
+    trees = ((50, 50, 5), (180, 200, 6), (300, 450, 4), (420, 250, 7), (80, 400, 5), (450, 50, 4),
+             (200, 80, 5), (350, 350, 6))
+    per = int(20_000 * scale)
+    for i, (cx, cy, r) in enumerate(trees):
+        nc = int(per * 0.8)
+        hx, hy, hz = hemisphere(nc, seed + 1000 + i, 1.0)
+        add(F(cx) + hx * F(r), F(cy) + hy * F(r), F(4.0) + hz * F(r), "canopy")
+        nt = per - nc
+        add(F(cx) + _normal(seed, nt, 0.15, st), F(cy) + _normal(seed, nt, 0.15, st + 2),
+            uniform(seed, nt, 0.0, 4.0, st + 4), "trunk")
+        st += 5
+    cols = (np.concatenate(xs), np.concatenate(ys), np.concatenate(zs))
+    return cols + (parts,) if with_parts else cols

@@ -3726,7 +3726,9 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         const Level &lv = order[li];
         pcrs_index *ix = lv.ix;
         const bool last_level = lv.next < 0;
-        const size_t list_elems = (size_t)m + 64;
+        // every query of a level is one of its own points, so its lists are as long as the level
+        // (not as the cloud: two dozen levels of a hundred million points would hold 50 GB)
+        const size_t list_elems = ix->nvalid + 64;
         const size_t need = (5 * list_elems + 64) * sizeof(uint32_t);
         if (ix->fail_lists.bytes < need) PCRS_HIP_CHECK(ctx, ix->fail_lists.alloc(ctx, need));
         uint32_t *listA = ix->fail_lists.as<uint32_t>();

@@ -16,7 +16,7 @@ shard = [eng.from_numpy(c) for c in cols]
 del cols
 mean, keep = eng.empty(n), eng.empty(n, "uint8")
 nx, ny, nz = eng.empty(n), eng.empty(n), eng.empty(n)
-tb, ts = [], []
+tb, ts, td = [], [], []
 for rep in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ix = eng.build_index(*shard, 17)
@@ -25,7 +25,9 @@ for rep in range(4):
     thr, ok, n_keep = eng.select(mean, 1.0, mean, keep)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     st = eng.index_stats(ix)
+    t3 = time.perf_counter()
     eng.destroy_index(ix)
-    tb.append(t1 - t0); ts.append(t2 - t1)
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    tb.append(t1 - t0); ts.append(t2 - t1); td.append(t4 - t3)
 print(f"{n} points: build {1e3 * np.median(tb[1:]):.1f} ms, search + statistics {1e3 * np.median(ts[1:]):.1f} ms, "
-      f"stages {st}, kept {n_keep}", flush=True)
+      f"release {1e3 * np.median(td[1:]):.1f} ms, stages {st}, kept {n_keep}", flush=True)

@@ -317,13 +317,18 @@ __global__ __launch_bounds__(GB_THREADS) void scatter_kernel(const float *x, con
 struct SortPlan {
     GridGeom g;
     BoxFilter box;     // points outside it are left out, like the non-finite ones
-    uint32_t shift;    // log2(cells per coarse bucket), <= FINE_MAX_SHIFT
+    uint32_t shift;    // log2(cells per coarse bucket), <= FINE_BIG_SHIFT
     uint32_t nb;       // coarse buckets
     uint32_t nblk;     // level-1 blocks
     uint32_t per_blk;  // points per level-1 block
     uint32_t ncell;
 };
 constexpr uint32_t FINE_MAX_SHIFT = 12;
+// Grids of more cells than 8192 buckets of 2^12 (a flat scene of a hundred million points: most
+// of its layers of cells are empty) get buckets of up to 2^15 cells: 128 KB of counters, one
+// block per CU, no staging array -- still far cheaper than the one-level sort's device-scope
+// atomic per point and pass.
+constexpr uint32_t FINE_BIG_SHIFT = 15;
 
 __global__ __launch_bounds__(GB_THREADS) void coarse_hist_kernel(const float *x, const float *y,
                                                                  const float *z, uint32_t m,
@@ -399,13 +404,15 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_scatter_kernel(const float 
     }
 }
 
+template <uint32_t MAXSHIFT>
 __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp, SortPlan sp,
                                                                const uint32_t *table,
                                                                uint32_t *cell_start, float4 *spts,
                                                                float *spts3, uint32_t *nonempty) {
     // spts3 (nullable): the same points without their index, 12 bytes apart (what the
     // lane-per-query search kernel reads)
-    __shared__ uint32_t cnt[1u << FINE_MAX_SHIFT];
+    constexpr bool STAGED = MAXSHIFT <= FINE_MAX_SHIFT;
+    __shared__ uint32_t cnt[1u << MAXSHIFT];
     __shared__ uint32_t wsum[GB_THREADS / 64];
     const uint32_t b = blockIdx.x;
     const uint32_t cpb = 1u << sp.shift;
@@ -496,8 +503,8 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     // thousands of blocks each scattering 16-byte points over their own window of the output
     // overflow the L2 once the windows together exceed it, and every partial line costs a
     // read-modify-write.
-    __shared__ float4 stage[FINE_HELD * GB_THREADS];
-    if (end - begin <= FINE_HELD * GB_THREADS) {
+    __shared__ float4 stage[STAGED ? FINE_HELD * GB_THREADS : 1];
+    if (STAGED && end - begin <= FINE_HELD * GB_THREADS) {
 #pragma unroll
         for (int h = 0; h < FINE_HELD; ++h) {
             const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
@@ -2541,7 +2548,7 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp, uint
     if (ncell > (nb_max << FINE_MAX_SHIFT)) nb_max = 8192u;
     uint32_t shift = 0;
     while (((ncell + (1u << shift) - 1) >> shift) > nb_max) ++shift;
-    if (shift > FINE_MAX_SHIFT) return false;
+    if (shift > FINE_BIG_SHIFT) return false;
     sp->g = g;
     sp->box = pcrs_no_box();
     sp->shift = shift;
@@ -2589,8 +2596,12 @@ static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, con
     }
     hipLaunchKernelGGL(coarse_scatter_kernel, dim3(sp.nblk), dim3(GB_THREADS),
                        sp.nb * sizeof(uint32_t), ctx->stream, x, y, z, m, sp, table, tmp);
-    hipLaunchKernelGGL(fine_sort_kernel, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp, sp,
-                       table, cell_start, sorted, sorted3, d_nonempty);
+    if (sp.shift <= FINE_MAX_SHIFT)
+        hipLaunchKernelGGL(fine_sort_kernel<FINE_MAX_SHIFT>, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp,
+                           sp, table, cell_start, sorted, sorted3, d_nonempty);
+    else
+        hipLaunchKernelGGL(fine_sort_kernel<FINE_BIG_SHIFT>, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp,
+                           sp, table, cell_start, sorted, sorted3, d_nonempty);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

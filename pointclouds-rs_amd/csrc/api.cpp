@@ -280,6 +280,13 @@ void pcrs_ctx_destroy(pcrs_ctx *ctx) try {
         (void)hipStreamDestroy(ctx->copy_stream);
     }
     if (ctx->copy_event) (void)hipEventDestroy(ctx->copy_event);
+    for (hipStream_t st : ctx->side_streams)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    for (hipEvent_t e : ctx->level_events) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 } catch (...) {

@@ -568,7 +568,16 @@ __device__ __forceinline__ bool slot_is_query(const SlotChoice &ch, const float4
         own = own && point_taken(ch.in, p.x, p.y, p.z);
         for (int j = 0; j < ch.n_ex; ++j) own = own && !point_taken(ch.ex[j], p.x, p.y, p.z);
     }
-    if (ch.handed) own = own || ch.handed[orig] == ch.level;
+    if (ch.handed) {
+        // a grid with finer grids under it is only handed points of their boxes: a pass that
+        // takes nothing else need not look up the byte of any other point
+        bool maybe = true;
+        if (ch.no_own && ch.boxes && ch.n_ex > 0) {
+            maybe = false;
+            for (int j = 0; j < ch.n_ex; ++j) maybe = maybe || point_taken(ch.ex[j], p.x, p.y, p.z);
+        }
+        if (maybe) own = own || ch.handed[orig] == ch.level;
+    }
     return own;
 }
 
@@ -1747,6 +1756,15 @@ __global__ __launch_bounds__(GB_THREADS) void knn_wave_kernel(CellArgs a, KnnOut
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lists are reused next round
+    }
+}
+
+// total[0] += *entries, total[3] += *left (nullable): the stage counters of one level of a refined
+// index joining the search's totals.
+__global__ void add_counts_kernel(uint32_t *total, const uint32_t *entries, const uint32_t *left) {
+    if (threadIdx.x == 0) {
+        atomicAdd(&total[0], *entries);
+        if (left) atomicAdd(&total[3], *left);
     }
 }
 
@@ -3711,7 +3729,9 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     std::vector<bool> is_target(order.size(), false);  // some level hands on to it
     for (const Level &l : order)
         if (l.next >= 0) is_target[(size_t)l.next] = true;
-    std::vector<SlotChoice> choices(order.size());
+    size_t top_pos = 0;
+    while (order[top_pos].ix != top) ++top_pos;
+    std::vector<SlotChoice> choices(order.size() + 1);
     for (size_t li = 0; li < order.size(); ++li) {
         const Level &lv = order[li];
         SlotChoice ch{};
@@ -3726,17 +3746,98 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         ch.level = (uint8_t)li;
         choices[li] = ch;
     }
+    choices[order.size()] = choices[top_pos];  // the index's own grid without what it is handed
+    choices[order.size()].handed = nullptr;
     if (!top->level_choices.p) {  // the levels of an index never change: uploaded once
         PCRS_HIP_CHECK(ctx, top->level_choices.alloc(ctx, choices.size() * sizeof(SlotChoice)));
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(top->level_choices.p, choices.data(), choices.size() * sizeof(SlotChoice),
                                            hipMemcpyHostToDevice, ctx->stream));
         PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    // Grids that do not depend on each other -- the finer grids under one grid, each with the
+    // tail of its slowest lane and a wave-kernel lifetime -- run on side streams: a grid on the
+    // stream of the first finer grid under it (or, with none, on the next stream in turn), behind
+    // the events of the others; the index's own grid and the coarser ones on the context's stream.
+    static const bool streams_on = [] {  // experiments only: PCRS_GRID_STREAMS=0
+        const char *e = getenv("PCRS_GRID_STREAMS");
+        return !(e && e[0] == '0');
+    }();
+    const bool side = streams_on && top_pos >= 2;
+    // The index's own grid answers most of the cloud and waits for nobody with its own queries:
+    // those go first, on the context's stream, while the finer grids run beside them; what the
+    // finer grids hand to it is a second, small pass behind them.  (Not when the caller wants the
+    // uncertified queries back as one list and this grid is the last: two passes, two lists.)
+    // Nor for clouds of tens of millions of points: their finer grids are many and large enough to
+    // fill the GPU between them, and the second pass costs a scan of this grid's slots (100 M
+    // points: 49 ms without the split, 53 ms with it; 24 M: 15.1 / 14.2 ms; the 200 K-point blob,
+    // whose chain of finer grids is hidden behind this grid's own queries: 4.8 / 3.45 ms).
+    const bool split = side && !(order[top_pos].next < 0 && q.no_brute) && top->nvalid <= (32u << 20);
+    std::vector<int> lane_of(order.size(), 0);  // 0: the context's stream, 1..: a side stream
+    std::vector<std::vector<int>> under(order.size());
+    hipStream_t const main_stream = ctx->stream;
+    struct Rejoin {  // whatever happens, no side stream is left with work the caller cannot see
+        pcrs_ctx *ctx;
+        hipStream_t main_stream;
+        bool armed;
+        ~Rejoin() {
+            ctx->stream = main_stream;
+            if (armed)
+                for (hipStream_t st : ctx->side_streams)
+                    if (st) (void)hipStreamSynchronize(st);
+        }
+    } rejoin{ctx, main_stream, false};
+    bool lane_forked[pcrs_ctx::kSideStreams + 1] = {true, false, false, false};
+    if (side) {
+        for (int i = 0; i < pcrs_ctx::kSideStreams; ++i)
+            if (!ctx->side_streams[i]) {
+                    // ahead of the context's stream where the two compete: the finer grids are small,
+                    // and the grid above them waits for them
+                    int least = 0, greatest = 0;
+                    PCRS_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    PCRS_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->side_streams[i], hipStreamNonBlocking,
+                                                                    greatest));
+                }
+        if (!ctx->fork_event) PCRS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+        while (ctx->level_events.size() < top_pos) {
+            hipEvent_t e = nullptr;
+            PCRS_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->level_events.push_back(e);
+        }
+        for (size_t li = 0; li < top_pos; ++li) under[(size_t)order[li].next].push_back((int)li);
+        int turn = 0;
+        for (size_t li = 0; li < top_pos; ++li)
+            lane_of[li] = !under[li].empty() ? lane_of[(size_t)under[li][0]]
+                          : split            ? 1 + (turn++) % pcrs_ctx::kSideStreams
+                                             : (turn++) % (pcrs_ctx::kSideStreams + 1);
+        rejoin.armed = true;
+    }
+    auto stream_of = [&](size_t li) {
+        return lane_of[li] == 0 ? main_stream : ctx->side_streams[lane_of[li] - 1];
+    };
+    // What the searches report (pcrs_index_last_stats): the entries of every level's wave kernel
+    // added up in word 0, what was left for the brute-force kernel in word 3.
+    if (!top->level_stats.p) PCRS_HIP_CHECK(ctx, top->level_stats.alloc(ctx, 16 * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, hipMemsetAsync(top->level_stats.p, 0, 16 * sizeof(uint32_t), main_stream));
+    if (side) PCRS_HIP_CHECK(ctx, hipEventRecord(ctx->fork_event, main_stream));
+    uint32_t *level_stats = top->level_stats.as<uint32_t>();
     const uint32_t *esc_list = nullptr, *esc_count = nullptr;  // what the last level left
-    for (size_t li = 0; li < order.size(); ++li) {
+    // One level's stages.  mode 0: its own queries and what it is handed; 1: its own only (waits
+    // for nobody); 2: only what it is handed.
+    auto run_level = [&](size_t li, int mode) -> int {
         const Level &lv = order[li];
         pcrs_index *ix = lv.ix;
         const bool last_level = lv.next < 0;
+        if (side) {
+            ctx->stream = stream_of(li);
+            if (!lane_forked[lane_of[li]]) {
+                PCRS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->fork_event, 0));
+                lane_forked[lane_of[li]] = true;
+            }
+            if (mode != 1)
+                for (int d : under[li])
+                    if (lane_of[(size_t)d] != lane_of[li])
+                        PCRS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->level_events[(size_t)d], 0));
+        }
         // every query of a level is one of its own points, so its lists are as long as the level
         // (not as the cloud: two dozen levels of a hundred million points would hold 50 GB)
         const size_t list_elems = ix->nvalid + 64;
@@ -3765,8 +3866,12 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         // most of its points: its lanes go over all its slots and test each (three launches over
         // the level's points less, and no list to read); one that only takes what it is handed
         // gets a compacted list.
-        const bool filtered = lv.own;
-        if (!filtered) PCRS_TRY(choose_slots(ix, choices[li], listS, &counters[4]));
+        const bool filtered = lv.own && mode != 2;
+        if (!filtered) {
+            SlotChoice ch = choices[li];
+            if (mode == 2) ch.no_own = true;
+            PCRS_TRY(choose_slots(ix, ch, listS, &counters[4]));
+        }
 
         CellArgs a{};
         a.g = ix->g;
@@ -3787,7 +3892,10 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         a.kcollect = collect ? (kc ? kc : 1) : 0;
         a.useful_d2 = __builtin_inff();
         a.R = 1;
-        a.heavy = m >= PCRS_HEAVY_FLAG ? 0xFFFFFFFFu : 8192u;
+        // (The few queries the finer grids hand to a second pass of their own sit at the rims of
+        // crowded regions: a lane walks a cube of thousands of points for milliseconds, and with
+        // nothing else in the launch to hide behind that is the launch.  A wave each serves them.)
+        a.heavy = m >= PCRS_HEAVY_FLAG ? 0xFFFFFFFFu : (mode == 2 ? 1024u : 8192u);
         // a cube with fewer than three lists' worth of points that certifies nothing: a sparse spot
         a.sparse_below = (lv.pass_sparse && !last_level) ? 3u * keff : 0u;
         a.hand_flags = last_level ? nullptr : hand;
@@ -3811,7 +3919,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         if (filtered) {
             a.qmode = 5;
             a.nq = (uint32_t)ix->nvalid;
-            a.choice = top->level_choices.as<SlotChoice>() + li;
+            a.choice = top->level_choices.as<SlotChoice>() + (mode == 1 ? order.size() : li);
         } else {
             a.qmode = 3;
             a.qlist = listS;
@@ -3819,7 +3927,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         }
         pcrs_timing_begin(ctx);
         launch_lane_kernel(ctx, a, out, kb, collect,
-                           lv.own ? lane_blocks : std::min(lane_blocks, (unsigned)ctx->num_cus * 16u));
+                           filtered ? lane_blocks : std::min(lane_blocks, (unsigned)ctx->num_cus * 16u));
         pcrs_timing_end(ctx);
         ix->counter_phase ^= 1;
         a.zero_me = nullptr;
@@ -3847,12 +3955,22 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         a.heavy_only = (pass_up && lv.own && lv.ix != top) ? 1u : 0u;
         launch_wave_kernel(ctx, a, out, kb, collect,
                            (unsigned)std::min<size_t>(((size_t)m + 3) / 4, (size_t)ctx->num_cus * 8));
+        hipLaunchKernelGGL(add_counts_kernel, dim3(1), dim3(64), 0, ctx->stream, level_stats, &counters[0],
+                           last_level ? &counters[3] : nullptr);
         PCRS_HIP_CHECK(ctx, hipGetLastError());
         ix->left_list = listB;
         ix->left_count = &counters[3];
         esc_list = listB;
         esc_count = &counters[3];
+        if (mode == 1 && last_level) {
+            // nothing comes after this grid: what its own queries leave is answered here and now,
+            // before the second pass takes the lists
+            PCRS_TRY(pcrs_launch_knn_bf(ctx, top->x, top->y, top->z, top->m, q, out, kneed, esc_list, esc_count,
+                                        m));
+        }
         ctx->timing = timing_was;
+        if (side && li < top_pos && lane_of[(size_t)lv.next] != lane_of[li])
+            PCRS_HIP_CHECK(ctx, hipEventRecord(ctx->level_events[li], ctx->stream));
         static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
         if (debug) {
             uint32_t c[8];
@@ -3863,8 +3981,13 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
                             "lanes to the wave kernel, %u left for brute force (last level)\n",
                     li, (double)ix->g.cell, ix->nvalid, c[4], c[5], c[0], c[3]);
         }
-    }
+        return PCRS_OK;
+    };
+    if (split) PCRS_TRY(run_level(top_pos, 1));
+    for (size_t li = 0; li < order.size(); ++li) PCRS_TRY(run_level(li, split && li == top_pos ? 2 : 0));
     // what even the coarsest level (no open faces) could not certify: more ties than a wave lists
+    ctx->stream = main_stream;  // every side stream has been waited for by the grid above its grids
+    rejoin.armed = false;
     ctx->timing = false;
     const int rc_bf = q.no_brute ? PCRS_OK
                                  : pcrs_launch_knn_bf(ctx, top->x, top->y, top->z, top->m, q, out, kneed,
@@ -3877,7 +4000,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         PCRS_TRY(pcrs_launch_invalid_defaults(ctx, top->x, top->y, top->z, q, out_in));
     top->left_list = esc_list;
     top->left_count = esc_count;
-    top->stats_dev = top->counters.as<uint32_t>() + 16 * (top->counter_phase ^ 1);
+    top->stats_dev = level_stats;
     top->stats_nq = m;
     return PCRS_OK;
 }

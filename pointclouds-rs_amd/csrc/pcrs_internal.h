@@ -38,6 +38,14 @@ struct pcrs_ctx {
     // (created on first use); copy_event orders it behind the producing kernels
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_event = nullptr;
+    // Side streams for the grids of a refined index that do not depend on each other (grid.hip,
+    // launch_knn_levels; created on first use).  fork_event orders them behind the context's
+    // stream, level_events order a grid behind the finer ones under it; all of them have joined
+    // the context's stream again when the search returns.
+    static constexpr int kSideStreams = 3;
+    hipStream_t side_streams[kSideStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    std::vector<hipEvent_t> level_events;
     // optional HIP-event bracketing of the neighbour-search kernel (benchmark instrumentation)
     bool timing = false;
     std::vector<hipEvent_t> ev_start, ev_stop;  // one pair per bracketed launch
@@ -224,6 +232,7 @@ struct pcrs_index {
     // a byte per point of the columns, for a search over the chain of grids: the level a query
     // that one level could not answer is meant for next
     DevBuf hand_flags;
+    DevBuf level_stats;    // what the last search over the levels reports (16 words)
     DevBuf level_choices;  // the query test of every level (grid.hip: SlotChoice), in the order they run
     double aim = 0.0;  // points per occupied cell the build aimed at
     // of the accepted sort, when it read them back: mean points per occupied cell, and the

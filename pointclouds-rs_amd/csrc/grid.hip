@@ -3145,7 +3145,10 @@ int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth) {
         }
         one.points = ds.points;
         one.cells = ds.cells;
-        if (volume(one) <= 0.3 * whole) regions.push_back(one);
+        // one box, if it is a small part of the grid and the crowded cells are not mere specks in
+        // it (four clusters in four corners of a field: eighteen cells in a box of twelve thousand)
+        if (volume(one) <= 0.3 * whole && (volume(one) <= 64.0 || (double)one.cells >= 0.01 * volume(one)))
+            regions.push_back(one);
     }
     if (regions.empty()) {
         // Crowded cells all over the grid (the roofs and trees of a survey, the cars of a street):

@@ -123,6 +123,19 @@ def blob_in_box(n_blob, n_background, seed=0, sigma=1e-3, centre=3.0, half=100.0
     return tuple(np.ascontiguousarray(p[:, i]) for i in range(3))
 
 
+def clusters_in_field(n_each=40_000, n_background=150_000, seed=5, sigma=0.3, half=50.0):
+    """Four dense Gaussian clusters (a fraction of a unit across) far apart in a sparse uniform box
+    100 units wide, shuffled: crowded cells in four corners of any grid sized for the box, so that
+    one box around them is most of the grid."""
+    rng = np.random.default_rng(seed)
+    centres = np.array([[-30, -30, -30], [30, -30, -20], [-30, 30, 20], [25, 25, 30]], dtype=np.float64)
+    parts = [rng.normal(0, sigma, size=(n_each, 3)) + c for c in centres]
+    parts.append(rng.uniform(-half, half, size=(n_background, 3)))
+    p = np.concatenate(parts).astype(F)
+    p = p[rng.permutation(len(p))]
+    return tuple(np.ascontiguousarray(p[:, i]) for i in range(3))
+
+
 def _normal(seed, n, sigma, stream):
     """Normal deviates (Box-Muller over two SplitMix64 streams), float32."""
     u1 = (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))

@@ -1119,6 +1119,35 @@ def test_clouds_of_very_uneven_density_use_finer_and_coarser_levels_and_match_th
     assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx) and _bit_equal(dist, rdist)
 
 
+def test_several_crowded_regions_get_grids_of_their_own_and_match_the_oracle(hip, oracle):
+    """Four dense clusters far apart in a sparse field: one box around the crowded cells would be
+    most of the grid, so every cluster gets a finer grid of its own (side by side under the
+    index's grid, searched on streams of their own beside the index's own queries) and hands the
+    queries of its rim back.  Means, threshold, mask and lists must be the oracle's; the normals
+    within 1e-5."""
+    x, y, z = gen.clusters_in_field()   # 310 000 points
+    vp = (0.0, 0.0, 300.0)
+    k = 16
+    ix = hip.Index(x, y, z, k_hint=k + 1)
+    finer, coarser = ix.levels()
+    assert finer >= 4, (finer, coarser)
+    q = np.random.default_rng(3).choice(len(x), 3000, replace=False)
+    idx, dist, cnt = ix.knn(x[q], y[q], z[q], k + 1)
+    ix.close()
+    ridx, rdist, _, rcnt = oracle.knn(x, y, z, x[q], y[q], z[q], k + 1, algo=1)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx) and _bit_equal(dist, rdist)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, k, 1.0, algo=1)
+    ref = oracle.normals(x, y, z, k, vp, algo=1)
+    for _ in range(2):  # the second call finds the streams and the levels' buffers in place
+        keep, n_keep, thr, mean = hip.sor(x, y, z, k, 1.0)
+        bad = np.flatnonzero(mean.view(np.uint32) != rmean.view(np.uint32))
+        assert len(bad) == 0, (len(bad), bad[:5], mean[bad[:5]], rmean[bad[:5]])
+        assert _bit_equal(thr, rthr) and n_keep == rn and np.array_equal(keep, rkeep)
+        keep2, nk2, thr2, nrm = hip.sor_normals(x, y, z, k, 1.0, k, vp)
+        assert nk2 == rn and _bit_equal(thr2, rthr) and np.array_equal(keep2, rkeep)
+        assert normals_close(nrm, ref, 1e-5).mean() > 0.9999
+
+
 def test_aerial_scene_matches_the_oracle(hip, oracle):
     """A tenth of the reference's aerial example scene (examples/python/aerial_lidar.py:26-137:
     terrain surface, roofs and walls, canopies and trunks; 241 K points): SOR and normals against

@@ -2700,7 +2700,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         const char *e = getenv("PCRS_GRID_HINT");
         return !(e && e[0] == '0');
     }();
-    const pcrs_ctx::GridHint &gh = ctx->grid_hint;
+    pcrs_ctx::GridHint &gh = ix->level_key ? ctx->level_hints[ix->level_key] : ctx->grid_hint;
     bool hinted = false;
     // (Only for clouds that arrive in host memory: the ranks of a sharded run build their indices
     // over device columns and must all derive the same geometry from the cloud alone, whatever
@@ -2922,11 +2922,11 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     ix->g = g;
     ix->ncell = ncell;
     if (!fixed_cell) {
-        ctx->grid_hint.cell = cell;
-        ctx->grid_hint.emax = emax;
-        ctx->grid_hint.dim = dim;
-        ctx->grid_hint.n = nvalid;
-        ctx->grid_hint.k_hint = k_hint;
+        gh.cell = cell;
+        gh.emax = emax;
+        gh.dim = dim;
+        gh.n = nvalid;
+        gh.k_hint = k_hint;
     }
     if (from_src) {  // the sort numbered the gathered points: back to the cloud's own indices
         hipLaunchKernelGGL(remap_index_kernel, dim3((unsigned)((nvalid + GB_THREADS - 1) / GB_THREADS)),
@@ -3292,6 +3292,10 @@ int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth) {
         child->m = ix->m;
         child->k_hint = k_hint;
         child->box = pbox;
+        // a finer grid of a cloud like the one before it starts from the cell that one's grid at
+        // this place in the tree ended with (only a starting point, as for the index itself)
+        child->level_key = ix->level_key * 31u + (uint32_t)(&r - regions.data()) + 1u;
+        child->use_hint = true;
         // (only where the region is a small part of the cloud: gathering costs a read-back of its
         // own, and three passes over a cloud of a million points cost less than that)
         if ((double)r.points * 8.0 < (double)ix->m) {

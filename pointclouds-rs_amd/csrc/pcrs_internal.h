@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/pcrs_hip.h"
@@ -67,6 +68,11 @@ struct pcrs_ctx {
         size_t n = 0;
         uint32_t k_hint = 0;
     } grid_hint;
+    // The same for the finer grids of a refined index, by their place in the tree (pcrs_index::
+    // level_key): the second scan of a sensor's stream builds every level in one sizing attempt,
+    // where the first needed two or three.  (Kept apart from grid_hint, which a finer grid's build
+    // would otherwise overwrite with a geometry no whole cloud can use.)
+    std::map<uint32_t, GridHint> level_hints;
 };
 
 hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap);
@@ -188,6 +194,7 @@ struct pcrs_index {
     // bounds that hold every point the grid takes and an upper limit of their number, from a
     // caller that has just measured the cloud: the build then skips its own pass for them
     bool use_hint = false;  // start from the context's last geometry although the columns are device memory
+    uint32_t level_key = 0;  // place in the tree of a refined index: 0 the index itself, else parent * 31 + ordinal + 1
     bool have_bounds = false;
     double bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
     size_t bounds_n_upper = 0;

@@ -3043,6 +3043,117 @@ static int scan_cells(pcrs_index *ix, uint32_t threshold, uint32_t k_short, Dens
     return PCRS_OK;
 }
 
+// ---- a grid of cells three times as wide, out of the cells of the grid it stands behind
+// Same origin, so a wide cell is 3 x 3 x 3 of the fine ones and its points are nine runs of up to
+// three consecutive fine cells in the sorted array: count, scan, copy -- no sort.  (A sort of the
+// same points by cells 27 times as full leaves a few buckets with most of the points: 0.2 ms for
+// the coarser grid of a ring scan of a million points.)  A point's wide cell is the one its fine
+// cell lies in, which can differ from the cell its coordinates compute to by the rounding of one
+// multiplication: the same slack that every certificate already allows for a point's own cell.
+__global__ __launch_bounds__(GB_THREADS) void wide_count_kernel(const uint32_t *cell_start, GridGeom g,
+                                                                GridGeom w, uint32_t wcells, uint32_t *count) {
+    const uint32_t c = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (c >= wcells) return;
+    const int X = (int)(c % (uint32_t)w.nx), Y = (int)((c / (uint32_t)w.nx) % (uint32_t)w.ny);
+    const int Z = (int)(c / ((uint32_t)w.nx * (uint32_t)w.ny));
+    uint32_t total = 0;
+    const int x0 = 3 * X, x1 = min(3 * X + 2, g.nx - 1);
+    if (x0 < g.nx)
+        for (int z = 3 * Z; z <= min(3 * Z + 2, g.nz - 1); ++z)
+            for (int y = 3 * Y; y <= min(3 * Y + 2, g.ny - 1); ++y) {
+                const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+                total += cell_start[row + x1 + 1] - cell_start[row + x0];
+            }
+    count[c] = total;
+}
+
+// One thread per slot of the wide grid's sorted array: its wide cell by bisection of the slot
+// ranges, then the run of fine cells it falls into.
+__global__ __launch_bounds__(GB_THREADS) void wide_gather_kernel(const uint32_t *cell_start, GridGeom g,
+                                                                 const float4 *spts, GridGeom w, uint32_t wcells,
+                                                                 const uint32_t *wstart, uint32_t n,
+                                                                 float4 *out, float *out3) {
+    const uint32_t s = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (s >= n) return;
+    uint32_t lo = 0, hi = wcells;  // the last cell with wstart[c] <= s
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (wstart[mid] <= s) lo = mid; else hi = mid;
+    }
+    const uint32_t c = lo;
+    uint32_t local = s - wstart[c];
+    const int X = (int)(c % (uint32_t)w.nx), Y = (int)((c / (uint32_t)w.nx) % (uint32_t)w.ny);
+    const int Z = (int)(c / ((uint32_t)w.nx * (uint32_t)w.ny));
+    const int x0 = 3 * X, x1 = min(3 * X + 2, g.nx - 1);
+    uint32_t src = 0xFFFFFFFFu;
+    for (int z = 3 * Z; z <= min(3 * Z + 2, g.nz - 1) && src == 0xFFFFFFFFu; ++z)
+        for (int y = 3 * Y; y <= min(3 * Y + 2, g.ny - 1); ++y) {
+            const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+            const uint32_t b = cell_start[row + x0], len = cell_start[row + x1 + 1] - b;
+            if (local < len) {
+                src = b + local;
+                break;
+            }
+            local -= len;
+        }
+    if (src == 0xFFFFFFFFu) return;  // cannot happen: the counts are the sums of these runs
+    const float4 p = spts[src];
+    out[s] = p;
+    if (out3) {
+        out3[(size_t)s * 3] = p.x;
+        out3[(size_t)s * 3 + 1] = p.y;
+        out3[(size_t)s * 3 + 2] = p.z;
+    }
+}
+
+// Fills `c` (bounds, box and columns set by the caller) with the grid of cells three times as wide
+// as ix's.  *done = false when the geometry does not come out as 3 x 3 x 3 of ix's cells (the
+// caller then sorts).
+static int wide_grid_from_cells(pcrs_index *ix, pcrs_index *c, bool *done) {
+    pcrs_ctx *ctx = ix->ctx;
+    const GridGeom &g = ix->g;
+    *done = false;
+    double lo[3], ext[3], emax = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = c->bounds_lo[a];
+        ext[a] = c->bounds_hi[a] - c->bounds_lo[a];
+        emax = std::max(emax, ext[a]);
+    }
+    GridGeom w{};
+    uint32_t wcells = 0;
+    const double want = (double)(3.0f * g.cell);
+    double used = want;
+    make_geometry(lo, ext, emax, want, 4.0 * (double)ix->nvalid + 4096.0, &w, &wcells, &used);
+    if (used != want || w.ox != g.ox || w.oy != g.oy || w.oz != g.oz || 3 * w.nx < g.nx || 3 * w.ny < g.ny ||
+        3 * w.nz < g.nz || ix->nvalid >= 0xFFFFFFFFull)
+        return PCRS_OK;
+    for (int a = 0; a < 3; ++a) {  // the same origin: the same faces are open
+        w.open_lo[a] = g.open_lo[a];
+        w.open_hi[a] = g.open_hi[a];
+    }
+    const uint32_t n = (uint32_t)ix->nvalid;
+    DevBuf sums;
+    PCRS_HIP_CHECK(ctx, c->cell_start.alloc(ctx, (nonempty_slot(wcells) + 8) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, sums.alloc(ctx, ((size_t)wcells / 1024 + 4) * sizeof(uint32_t)));
+    PCRS_HIP_CHECK(ctx, c->spts.alloc(ctx, (size_t)n * sizeof(float4)));
+    PCRS_HIP_CHECK(ctx, c->spts3.alloc(ctx, (size_t)n * 3 * sizeof(float)));
+    uint32_t *wstart = c->cell_start.as<uint32_t>();
+    hipLaunchKernelGGL(wide_count_kernel, dim3((wcells + GB_THREADS - 1) / GB_THREADS), dim3(GB_THREADS), 0,
+                       ctx->stream, ix->cell_start.as<uint32_t>(), g, w, wcells, wstart);
+    PCRS_TRY(pcrs_launch_scan_u32(ctx, wstart, wcells, sums.as<uint32_t>(), wstart + wcells));
+    hipLaunchKernelGGL(wide_gather_kernel, dim3((n + GB_THREADS - 1) / GB_THREADS), dim3(GB_THREADS), 0,
+                       ctx->stream, ix->cell_start.as<uint32_t>(), g, ix->spts.as<float4>(), w, wcells, wstart, n,
+                       c->spts.as<float4>(), c->spts3.as<float>());
+    PCRS_HIP_CHECK(ctx, hipGetLastError());
+    c->g = w;
+    c->ncell = wcells;
+    c->nvalid = ix->nvalid;
+    c->aim = ix->aim;
+    c->algo = PCRS_ALGO_GRID;
+    *done = true;
+    return PCRS_OK;
+}
+
 constexpr int kCoarseMaxDepth = 3;
 static bool coarse_enabled() {
     static const bool on = [] {  // experiments only: PCRS_GRID_COARSE=0
@@ -3088,7 +3199,14 @@ static int grid_coarsen(pcrs_index *ix, uint32_t k_hint, unsigned long long shor
         const float v = e ? (float)atof(e) : 0.0f;
         return v >= 1.6f && v <= 8.0f ? v : 3.0f;
     }();
-    const int rc = pcrs_grid_build(c, k_hint, coarse_ratio * g.cell);
+    bool from_cells = false;
+    static const bool wide_from_cells = [] {  // experiments only: PCRS_GRID_COARSE_SORT=1 sorts instead
+        const char *e = getenv("PCRS_GRID_COARSE_SORT");
+        return !(e && e[0] == '1');
+    }();
+    int rc = PCRS_OK;
+    if (coarse_ratio == 3.0f && wide_from_cells) rc = wide_grid_from_cells(ix, c, &from_cells);
+    if (rc == PCRS_OK && !from_cells) rc = pcrs_grid_build(c, k_hint, coarse_ratio * g.cell);
     static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
     if (debug)
         fprintf(stderr, "pcrs grid coarse level %d: %llu of %zu points in cubes of fewer than %u points; "

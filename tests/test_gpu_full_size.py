@@ -139,6 +139,65 @@ def test_clustered_3m_sampled_parity():
     assert float((ln - 1.0).abs().max().item()) <= 1e-5
 
 
+@pytest.mark.timeout(600)
+def test_survey_scene_24m_sampled_parity():
+    """The survey scene of the benchmark's second c4 line at 24 M points (terrain, roofs, walls,
+    canopies, trunks): the index gives the crowded regions finer grids of their own, searches them
+    side by side on streams of its own, and answers its own queries beside them.  Samples of the
+    means from every kind of surface against the brute-force kernel, on two builds in a row (the
+    second starts every grid from the geometry the first ended with), and the stage counters."""
+    import torch
+
+    from pointclouds_rs import _ffi, synth
+    from pointclouds_rs.dist import HipEngine
+
+    eng = HipEngine.shared(0)
+    k = 16
+    *cols_h, parts = synth.aerial_scene(10.0, 42, with_parts=True)
+    n = len(cols_h[0])
+    cols = [eng.from_numpy(c) for c in cols_h]
+    del cols_h
+    rng = np.random.default_rng(3)
+    picks = [rng.choice(n, size=512, replace=False)]
+    for name, begin, end in parts:  # every part of the scene, the crowded ones above all
+        picks.append(begin + rng.choice(end - begin, size=min(96, end - begin), replace=False))
+    sample = np.unique(np.concatenate(picks))
+    ns = len(sample)
+    st = torch.from_numpy(sample).to(eng.device)
+    q = [c[st].contiguous() for c in cols]
+    bf = C.c_void_p()
+    eng.ctx.check(eng.lib.pcrs_index_build_dev(eng.ctx.handle, *[eng._p(c) for c in cols], n, k + 1,
+                                               _ffi.ALGO_BRUTE, C.byref(bf)))
+    idx = eng.empty(ns * (k + 1), "int32"); dist = eng.empty(ns * (k + 1)); cnt = eng.empty(ns, "int32")
+    eng.ctx.check(eng.lib.pcrs_knn_batch_dev(bf, *[eng._p(c) for c in q], ns, k + 1, eng._p(idx),
+                                             eng._p(dist), eng._p(cnt)))
+    torch.cuda.synchronize()
+    eng.lib.pcrs_index_destroy(bf)
+    d = dist.cpu().numpy().reshape(ns, k + 1)
+    s = np.zeros(ns, dtype=F)
+    for j in range(1, k + 1):
+        s = (s + d[:, j]).astype(F)
+    ref = (s / F(k)).astype(F)
+
+    mean = eng.empty(n); nx = eng.empty(n); ny = eng.empty(n); nz = eng.empty(n)
+    for build in range(2):
+        mean.fill_(-1.0)
+        ix = eng.build_index(*cols, k + 1)
+        finer, coarser = C.c_uint32(), C.c_uint32()
+        eng.ctx.check(eng.lib.pcrs_index_levels(ix, C.byref(finer), C.byref(coarser)))
+        eng.sor_normals_range(ix, 0, n, k, k, (250.0, 250.0, 1000.0), mean, nx, ny, nz)
+        stages = eng.index_stats(ix)
+        eng.destroy_index(ix)
+        assert finer.value >= 5, (finer.value, coarser.value)
+        assert sum(stages) == n and stages[2] == 0
+        got = mean[st].cpu().numpy()
+        bad = np.flatnonzero(got.view(np.uint32) != ref.view(np.uint32))
+        assert len(bad) == 0, (build, len(bad), sample[bad[:5]], got[bad[:5]], ref[bad[:5]])
+        assert float(mean.min().item()) >= 0.0  # every point was answered
+        ln = nx * nx + ny * ny + nz * nz
+        assert float((ln - 1.0).abs().max().item()) <= 1e-5
+
+
 @pytest.mark.timeout(300)
 def test_c3_icp_100k_properties(oracle):
     """Point-to-plane ICP of two 100 K-point scans, 50 iterations (the registration the benchmark

@@ -2330,6 +2330,17 @@ __global__ __launch_bounds__(GB_THREADS) void dense_blocks_kernel(const uint32_t
     }
 }
 
+// Every stride-th point of the columns as columns of their own (x, y, z one after the other).
+__global__ __launch_bounds__(GB_THREADS) void strided_sample_kernel(const float *x, const float *y, const float *z,
+                                                                    uint32_t stride, uint32_t ms, float *out) {
+    const uint32_t i = blockIdx.x * GB_THREADS + threadIdx.x;
+    if (i >= ms) return;
+    const size_t src = (size_t)i * stride;
+    out[i] = x[src];
+    out[(size_t)ms + i] = y[src];
+    out[2 * (size_t)ms + i] = z[src];
+}
+
 // The points of a box of cells of a sorted grid as columns of their own (x, y, z and the index in
 // the cloud's columns), row by row: rows[r] = first slot of row r's run of cells, offs[r] = where
 // its points go (an exclusive scan of the run lengths, offs[nrows] = their sum).
@@ -2711,6 +2722,45 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         cell = gh.cell * pow((double)gh.n / (double)nvalid, 1.0 / gh.dim);
         hinted = true;
     }
+    // A cloud of tens of millions of points is sized on a sample first.  The start above takes
+    // the cloud for a volume that fills its box; a survey flight does not, and finding that out
+    // costs a sort of all its points (8 ms at 100 M).  Every 64th point, gathered into columns of
+    // their own, goes through this very function (two or three sorts of 1/64 of the points,
+    // a few hundred microseconds); the cell and the dimension it ends with, scaled to the full
+    // density, are where the cloud itself starts.  Only a starting point, like the remembered
+    // geometry: the build still checks the occupancy it gets.
+    double start_dim = hinted ? gh.dim : 3.0;
+    static const bool probe_on = [] {  // experiments only: PCRS_GRID_PROBE=0
+        const char *e = getenv("PCRS_GRID_PROBE");
+        return !(e && e[0] == '0');
+    }();
+    constexpr uint32_t kProbeKey = 0xFFFFFFFEu, kProbeStride = 64;
+    if (probe_on && !hinted && !fixed_cell && !from_src && ix->level_key != kProbeKey && nvalid >= (16u << 20)) {
+        pcrs_index probe;
+        probe.ctx = ctx;
+        probe.x = ix->x;
+        probe.y = ix->y;
+        probe.z = ix->z;
+        probe.m = ix->m;
+        probe.k_hint = k_hint;
+        probe.box = box;
+        probe.level_key = kProbeKey;
+        const uint32_t ms = m / kProbeStride;
+        PCRS_HIP_CHECK(ctx, probe.src_cols.alloc(ctx, (size_t)ms * 3 * sizeof(float)));
+        probe.src_n = ms;
+        hipLaunchKernelGGL(strided_sample_kernel, dim3((ms + GB_THREADS - 1) / GB_THREADS), dim3(GB_THREADS), 0,
+                           ctx->stream, bx, by, bz, kProbeStride, ms, probe.src_cols.as<float>());
+        PCRS_HIP_CHECK(ctx, hipGetLastError());
+        pcrs_ctx::GridHint &ph = ctx->level_hints[kProbeKey];
+        ph = pcrs_ctx::GridHint{};
+        const int prc = pcrs_grid_build(&probe, k_hint, 0.0f);
+        if (prc == PCRS_OK && probe.algo == PCRS_ALGO_GRID && ph.cell > 0.0 && ph.n >= 4096) {
+            cell = ph.cell * pow((double)ph.n / (double)nvalid, 1.0 / ph.dim);
+            start_dim = ph.dim;
+            hinted = true;
+        }
+        // (its pinned read-back area is this build's too: nothing of it is needed any more)
+    }
     // cell budget: 4 cells per point; experiments may override the factor
     double cells_per_point = 4.0;
     if (const char *e = getenv("PCRS_GRID_CELLS_PER_POINT")) {
@@ -2737,7 +2787,8 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
     ix->aim = P;
     double P_surface = 0.75 * (double)k_hint;
     P_surface = P_surface < P ? P : (P_surface > 64.0 ? 64.0 : P_surface);
-    double dim = hinted ? gh.dim : 3.0, prev_cell = 0.0, prev_occ = 0.0;
+    double dim = start_dim, prev_cell = 0.0, prev_occ = 0.0;
+    bool prev_is_seen = false;
     for (int attempt = 0;; ++attempt) {
         double used = cell;
         make_geometry(lo, ext, emax, cell, max_cells, &g, &ncell, &used);
@@ -2808,6 +2859,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             ix->occ_mean = occ;
             ix->occ_seen = (double)squares_seen / (double)nvalid - 1.0;
         }
+        bool occ_is_seen = false;  // which of the two measures `occ` holds in this attempt
         const bool leave_crowded_to_levels =
             two_level && levels_enabled() && k_hint > 1 && nvalid >= kLevelMinPoints &&
             (double)squares_seen / (double)nvalid - 1.0 > level_ratio() * occ;
@@ -2820,7 +2872,10 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             unsigned long long squares;
             memcpy(&squares, h_nonempty + 2, sizeof(squares));
             const double seen = (double)squares / (double)nvalid - 1.0;
-            if (seen > occ) occ = seen;
+            if (seen > occ) {
+                occ = seen;
+                occ_is_seen = true;
+            }
         }
         static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
         if (debug)
@@ -2838,7 +2893,9 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             // its 27-cell cubes cannot certify (a flat slab came out at 3.8 points per cell and
             // half of its queries in the retry stage), while the cube of a surface holds a third
             // of the cells: it can afford fuller ones.
-            if (prev_cell > 0.0 && prev_occ > 0.0 && occ > 0.0 &&
+            // (both attempts by the same measure: the mean of one against what a point sees in the
+            // other says nothing about the cloud)
+            if (prev_cell > 0.0 && prev_occ > 0.0 && occ > 0.0 && prev_is_seen == occ_is_seen &&
                 (prev_cell >= 1.25 * cell || cell >= 1.25 * prev_cell)) {
                 dim = log(prev_occ / occ) / log(prev_cell / cell);
                 dim = dim < 2.0 ? 2.0 : (dim > 3.0 ? 3.0 : dim);
@@ -2850,6 +2907,7 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
             }
             prev_cell = cell;
             prev_occ = occ;
+            prev_is_seen = occ_is_seen;
             const double aim = P + (3.0 - dim) * (P_surface - P);
             ix->aim = aim;
             if (occ >= 0.75 * aim && occ <= 1.6 * aim) break;
@@ -2929,9 +2987,10 @@ int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request) {
         gh.k_hint = k_hint;
     }
     if (from_src) {  // the sort numbered the gathered points: back to the cloud's own indices
-        hipLaunchKernelGGL(remap_index_kernel, dim3((unsigned)((nvalid + GB_THREADS - 1) / GB_THREADS)),
-                           dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(), (uint32_t)nvalid,
-                           ix->src_index.as<uint32_t>());
+        if (ix->src_index.p)  // (a sample taken to size a grid has none: nobody searches it)
+            hipLaunchKernelGGL(remap_index_kernel, dim3((unsigned)((nvalid + GB_THREADS - 1) / GB_THREADS)),
+                               dim3(GB_THREADS), 0, ctx->stream, ix->spts.as<float4>(), (uint32_t)nvalid,
+                               ix->src_index.as<uint32_t>());
         PCRS_HIP_CHECK(ctx, hipGetLastError());
         ix->src_cols.release();
         ix->src_index.release();

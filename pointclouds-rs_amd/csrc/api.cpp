@@ -88,6 +88,7 @@ hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap) {
     size_t want = bytes < (1u << 20) ? ((bytes + 65535) & ~(size_t)65535)
                                      : ((bytes + bytes / 8 + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1));
     hipError_t e = hipMalloc(p, want);
+    ++ctx->pool_mallocs;
     if (e != hipSuccess && !ctx->pool.empty()) {
         // give the pooled memory back and retry once
         (void)hipStreamSynchronize(ctx->stream);
@@ -101,13 +102,18 @@ hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap) {
 }
 
 void pcrs_pool_release(pcrs_ctx *ctx, void *p, size_t cap) {
-    if (ctx->pool.size() >= 64) {  // keep the pool bounded: drop the largest idle buffer
-        size_t big = 0;
+    // Keep the pool bounded, by dropping the smallest idle buffer: an index over a scene with two
+    // dozen crowded regions gives back two hundred buffers at once, and the ones worth keeping
+    // are the large ones (a sorted copy of 100 M points is 1.6 GB: allocating and freeing it
+    // costs milliseconds, and freeing waits for the stream).
+    if (ctx->pool.size() >= 1024) {
+        size_t small = 0;
         for (size_t i = 1; i < ctx->pool.size(); ++i)
-            if (ctx->pool[i].bytes > ctx->pool[big].bytes) big = i;
+            if (ctx->pool[i].bytes < ctx->pool[small].bytes) small = i;
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(ctx->pool[big].p);
-        ctx->pool[big] = ctx->pool.back();
+        (void)hipFree(ctx->pool[small].p);
+        ++ctx->pool_drops;
+        ctx->pool[small] = ctx->pool.back();
         ctx->pool.pop_back();
     }
     ctx->pool.push_back({p, cap});
@@ -272,6 +278,12 @@ void pcrs_ctx_destroy(pcrs_ctx *ctx) try {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (getenv("PCRS_POOL_DEBUG")) {  // experiments only
+        size_t bytes = 0;
+        for (auto &pe : ctx->pool) bytes += pe.bytes;
+        fprintf(stderr, "pcrs pool: %zu idle buffers, %.1f MB, %zu allocations from the device, %zu dropped\n",
+                ctx->pool.size(), (double)bytes / 1e6, ctx->pool_mallocs, ctx->pool_drops);
+    }
     for (auto &pe : ctx->pool) (void)hipFree(pe.p);
     for (hipEvent_t e : ctx->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_stop) (void)hipEventDestroy(e);

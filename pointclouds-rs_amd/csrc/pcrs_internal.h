@@ -59,6 +59,7 @@ struct pcrs_ctx {
         size_t bytes;
     };
     std::vector<PoolEntry> pool;
+    size_t pool_mallocs = 0, pool_drops = 0;  // how often the pool went to the device (experiments)
     // The grid geometry the last index build settled on (grid.hip): a caller that feeds one cloud
     // after another of the same kind -- frames of a sensor -- starts the next build from it and
     // usually needs one sizing attempt instead of three.  Only a starting point: every build

@@ -3822,12 +3822,13 @@ int pcrs_grid_gather_selected(pcrs_index *ix, float *ox, float *oy, float *oz, u
     return PCRS_OK;
 }
 
-// A search of the cloud's own points over an index with finer levels (pcrs_index::child).  Every
-// point is a query of the finest level whose query box holds it; the levels run finest first, each
-// with the stages of a single grid (lane-per-query kernel, two-walk kernel for what that hands
-// over, wave-per-query kernel for what neither certifies), and what a level cannot certify -- a
-// neighbourhood that reaches across an open face of its box -- joins the queries of the next
-// coarser one.  The outputs are indexed by point, so the levels simply fill the same arrays.
+// A search of the cloud's own points over an index with further grids (pcrs_index::kids, the
+// finer ones under a grid, and pcrs_index::coarse).  Every point is a query of the finest grid
+// whose query box holds it; every grid runs after the finer ones under it, each with the stages of
+// a single grid (lane-per-query kernel, two-walk kernel for what that hands over, wave-per-query
+// kernel for what neither certifies), and what a grid cannot certify -- a neighbourhood that
+// reaches across an open face of its box -- joins the queries of the grid above it.  The outputs
+// are indexed by point, so the grids simply fill the same arrays.
 static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &out_in,
                              uint32_t kneed) {
     pcrs_ctx *ctx = top->ctx;

@@ -319,7 +319,7 @@ int pcrs_launch_knn_bf(pcrs_ctx *ctx, const float *rx, const float *ry, const fl
 // ---- grid (grid.hip)
 // cell_request > 0 fixes the cell edge (enlarged only if the cell budget demands it)
 int pcrs_grid_build(pcrs_index *ix, uint32_t k_hint, float cell_request = 0.0f);
-// finer grids over the crowded part of a grid, level by level (see pcrs_index::child)
+// finer grids over the crowded part of a grid, level by level (see pcrs_index::kids)
 int pcrs_grid_refine(pcrs_index *ix, uint32_t k_hint, int depth = 0);
 // radius count over the grid: possible when the ball fits a cube of at most 7^3 cells
 bool pcrs_grid_radius_ok(const pcrs_index *ix, float radius);

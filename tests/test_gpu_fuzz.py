@@ -115,6 +115,57 @@ def test_random_clouds(hip, oracle, kind, seed):
     assert len(cl) == len(rcl) and all(np.array_equal(a, b) for a, b in zip(cl, rcl))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_uneven_clouds(hip, oracle, seed):
+    """Clouds large and uneven enough for the index to grow further grids: a sparse field with a
+    random handful of dense clusters, patches of plane and lines of very different sizes and
+    densities (some of them worth a finer grid of their own, some not, some nested in another's
+    box), a few non-finite points, random k.  SOR means, threshold and mask bit-exact against the
+    oracle; normals within 1e-5 away from the degenerate parts."""
+    rng = np.random.default_rng(7000 + seed)
+    half = float(rng.choice([20.0, 50.0, 200.0]))
+    parts = [rng.uniform(-half, half, size=(int(rng.integers(60_000, 120_000)), 3))]
+    clean = [np.ones(len(parts[0]), dtype=bool)]
+    for _ in range(int(rng.integers(2, 7))):
+        c = rng.uniform(-0.8 * half, 0.8 * half, size=3)
+        m = int(rng.choice([3_000, 12_000, 25_000, 40_000]))
+        kind = rng.choice(["ball", "plane", "line"])
+        sigma = half * float(rng.choice([2e-4, 2e-3, 1e-2]))
+        if kind == "ball":
+            p = rng.normal(0, sigma, size=(m, 3)) + c
+        elif kind == "plane":
+            p = np.concatenate([rng.uniform(-30 * sigma, 30 * sigma, size=(m, 2)),
+                                rng.normal(0, 0.02 * sigma, size=(m, 1))], 1) + c
+        else:
+            p = np.concatenate([rng.uniform(-100 * sigma, 100 * sigma, size=(m, 1)),
+                                rng.normal(0, 0.02 * sigma, size=(m, 2))], 1) + c
+        parts.append(p)
+        clean.append(np.full(m, kind == "ball"))
+    p = np.concatenate(parts).astype(F)
+    clean = np.concatenate(clean)
+    order = rng.permutation(len(p))
+    p, clean = p[order], clean[order]
+    bad = rng.random(len(p)) < 1e-3
+    p[bad, rng.integers(0, 3, int(bad.sum()))] = rng.choice([np.nan, np.inf, -np.inf], int(bad.sum()))
+    x, y, z = (np.ascontiguousarray(p[:, a]) for a in range(3))
+    k = int(rng.choice([5, 10, 16, 24]))
+    vp = (0.0, 0.0, 10.0 * half)
+    rkeep, rn, rthr, rmean = oracle.sor(x, y, z, k, 1.0, algo=1)
+    ref = oracle.normals(x, y, z, k, vp, algo=1)
+    for _ in range(2):  # the second build starts every grid from what the first ended with
+        keep, n_keep, thr, mean = hip.sor(x, y, z, k, 1.0)
+        badm = np.flatnonzero(mean.view(np.uint32) != rmean.view(np.uint32))
+        assert len(badm) == 0, (seed, k, len(badm), badm[:5], mean[badm[:5]], rmean[badm[:5]])
+        assert (F(thr) == F(rthr) or (np.isnan(thr) and np.isnan(rthr))) and n_keep == rn
+        assert np.array_equal(keep, rkeep)
+        keep2, nk2, thr2, nrm = hip.sor_normals(x, y, z, k, 1.0, k, vp)
+        assert nk2 == rn and np.array_equal(keep2, rkeep)
+        ok = np.ones(len(x), dtype=bool)
+        for a, b in zip(nrm, ref):
+            ok &= np.abs(a.astype(np.float64) - b) <= 1e-5
+        assert ok[clean & ~bad].mean() > 0.9999, (seed, k, ok[clean & ~bad].mean())
+
+
 @pytest.mark.parametrize("seed", range(5))
 @pytest.mark.parametrize("kind", KINDS)
 def test_random_clouds_runs_of_cells(kind, seed):

@@ -3232,7 +3232,11 @@ static int grid_coarsen(pcrs_index *ix, uint32_t k_hint, unsigned long long shor
         const char *e = getenv("PCRS_GRID_COARSE_MIN");
         return e ? (unsigned long long)atoll(e) : 8192ull;
     }();
-    if (short_points < std::max<unsigned long long>(coarse_min, ix->nvalid / 64)) return PCRS_OK;
+    static const unsigned long long coarse_part = [] {  // experiments only: PCRS_GRID_COARSE_PART=<1/part of the points>
+        const char *e = getenv("PCRS_GRID_COARSE_PART");
+        return e && atoll(e) > 0 ? (unsigned long long)atoll(e) : 64ull;
+    }();
+    if (short_points < std::max<unsigned long long>(coarse_min, ix->nvalid / coarse_part)) return PCRS_OK;
     if (std::max(g.nx, std::max(g.ny, g.nz)) < 12) return PCRS_OK;  // a handful of cells already
     pcrs_index *c = new (std::nothrow) pcrs_index();
     if (!c) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");

@@ -405,8 +405,8 @@ __global__ __launch_bounds__(GB_THREADS) void coarse_scatter_kernel(const float 
     }
 }
 
-template <uint32_t MAXSHIFT>
-__global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp, SortPlan sp,
+template <uint32_t MAXSHIFT, uint32_t T>
+__global__ __launch_bounds__(T) void fine_sort_kernel(const float4 *tmp, SortPlan sp,
                                                                const uint32_t *table,
                                                                uint32_t *cell_start, float4 *spts,
                                                                float *spts3, uint32_t *nonempty) {
@@ -414,14 +414,14 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     // lane-per-query search kernel reads)
     constexpr bool STAGED = MAXSHIFT <= FINE_MAX_SHIFT;
     __shared__ uint32_t cnt[1u << MAXSHIFT];
-    __shared__ uint32_t wsum[GB_THREADS / 64];
+    __shared__ uint32_t wsum[T / 64];
     const uint32_t b = blockIdx.x;
     const uint32_t cpb = 1u << sp.shift;
     const uint32_t cell0 = b << sp.shift;
     const uint32_t ncl = min(cpb, sp.ncell - cell0);
     const uint32_t begin = table[(size_t)b * sp.nblk];
     const uint32_t end = table[(size_t)(b + 1) * sp.nblk];  // the scan's total closes the table
-    for (uint32_t t = threadIdx.x; t < cpb; t += GB_THREADS) cnt[t] = 0;
+    for (uint32_t t = threadIdx.x; t < cpb; t += T) cnt[t] = 0;
     // the first FINE_HELD points of every thread stay in registers between the counting and the
     // placing pass (all their loads are in flight together); longer buckets are read twice
     constexpr int FINE_HELD = 8;
@@ -429,25 +429,25 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     uint32_t held_cell[FINE_HELD];
 #pragma unroll
     for (int h = 0; h < FINE_HELD; ++h) {
-        const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+        const uint32_t i = begin + threadIdx.x + (uint32_t)h * T;
         if (i < end) held[h] = tmp[i];
     }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < FINE_HELD; ++h) {
-        const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+        const uint32_t i = begin + threadIdx.x + (uint32_t)h * T;
         if (i < end) {
             held_cell[h] = cell_index(sp.g, held[h].x, held[h].y, held[h].z) - cell0;
             atomicAdd(&cnt[held_cell[h]], 1u);
         }
     }
-    for (uint32_t i = begin + threadIdx.x + FINE_HELD * GB_THREADS; i < end; i += GB_THREADS) {
+    for (uint32_t i = begin + threadIdx.x + FINE_HELD * T; i < end; i += T) {
         const float4 p = tmp[i];
         atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u);
     }
     __syncthreads();
     // exclusive scan of cnt[0..cpb): each thread owns cpb/256 consecutive cells
-    const uint32_t ipt = (cpb + GB_THREADS - 1) / GB_THREADS;
+    const uint32_t ipt = (cpb + T - 1) / T;
     const uint32_t f0 = threadIdx.x * ipt;
     uint32_t local = 0, opened = 0;
     unsigned long long squares = 0;  // sum of squared cell counts = points x occupancy seen by a point
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
         const uint32_t o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    __shared__ uint32_t wopen[GB_THREADS / 64];
-    __shared__ unsigned long long wsq[GB_THREADS / 64];
+    __shared__ uint32_t wopen[T / 64];
+    __shared__ unsigned long long wsq[T / 64];
     if (lane == 63) wsum[wave] = incl;
     for (int off = 32; off > 0; off >>= 1) {
         opened += __shfl_down(opened, off, 64);
@@ -478,11 +478,15 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // one atomic each per block; nonempty + 2 is 8-byte aligned
-        const uint32_t o = wopen[0] + wopen[1] + wopen[2] + wopen[3];
+        uint32_t o = 0;
+        unsigned long long sq = 0;
+        for (uint32_t w = 0; w < T / 64; ++w) {
+            o += wopen[w];
+            sq += wsq[w];
+        }
         if (o) {
             atomicAdd(nonempty, o);
-            atomicAdd(reinterpret_cast<unsigned long long *>(nonempty + 2),
-                      wsq[0] + wsq[1] + wsq[2] + wsq[3]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(nonempty + 2), sq);
         }
     }
     uint32_t run = begin + incl - local;
@@ -498,25 +502,25 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     if (b == sp.nb - 1 && threadIdx.x == 0) cell_start[sp.ncell] = end;
     __syncthreads();
     // the cell starts leave through consecutive lanes (each thread scanned consecutive cells)
-    for (uint32_t t = threadIdx.x; t < ncl; t += GB_THREADS) cell_start[cell0 + t] = cnt[t];
+    for (uint32_t t = threadIdx.x; t < ncl; t += T) cell_start[cell0 + t] = cnt[t];
     __syncthreads();
     // A bucket that fits the staging array is put in order in LDS and leaves as one linear copy:
     // thousands of blocks each scattering 16-byte points over their own window of the output
     // overflow the L2 once the windows together exceed it, and every partial line costs a
     // read-modify-write.
-    __shared__ float4 stage[STAGED ? FINE_HELD * GB_THREADS : 1];
-    if (STAGED && end - begin <= FINE_HELD * GB_THREADS) {
+    __shared__ float4 stage[STAGED ? FINE_HELD * T : 1];
+    if (STAGED && end - begin <= FINE_HELD * T) {
 #pragma unroll
         for (int h = 0; h < FINE_HELD; ++h) {
-            const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+            const uint32_t i = begin + threadIdx.x + (uint32_t)h * T;
             if (i < end) stage[atomicAdd(&cnt[held_cell[h]], 1u) - begin] = held[h];
         }
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < end - begin; t += GB_THREADS) spts[begin + t] = stage[t];
+        for (uint32_t t = threadIdx.x; t < end - begin; t += T) spts[begin + t] = stage[t];
         if (spts3) {
             const float *sf = reinterpret_cast<const float *>(stage);
             float *o3 = spts3 + (size_t)begin * 3;
-            for (uint32_t t = threadIdx.x; t < 3u * (end - begin); t += GB_THREADS)
+            for (uint32_t t = threadIdx.x; t < 3u * (end - begin); t += T)
                 o3[t] = sf[(t / 3u) * 4u + t % 3u];
         }
         return;
@@ -531,10 +535,10 @@ __global__ __launch_bounds__(GB_THREADS) void fine_sort_kernel(const float4 *tmp
     };
 #pragma unroll
     for (int h = 0; h < FINE_HELD; ++h) {
-        const uint32_t i = begin + threadIdx.x + (uint32_t)h * GB_THREADS;
+        const uint32_t i = begin + threadIdx.x + (uint32_t)h * T;
         if (i < end) put(atomicAdd(&cnt[held_cell[h]], 1u), held[h]);
     }
-    for (uint32_t i = begin + threadIdx.x + FINE_HELD * GB_THREADS; i < end; i += GB_THREADS) {
+    for (uint32_t i = begin + threadIdx.x + FINE_HELD * T; i < end; i += T) {
         const float4 p = tmp[i];
         put(atomicAdd(&cnt[cell_index(sp.g, p.x, p.y, p.z) - cell0], 1u), p);
     }
@@ -2630,11 +2634,11 @@ static int run_two_level_sort(pcrs_ctx *ctx, const float *x, const float *y, con
     hipLaunchKernelGGL(coarse_scatter_kernel, dim3(sp.nblk), dim3(GB_THREADS),
                        sp.nb * sizeof(uint32_t), ctx->stream, x, y, z, m, sp, table, tmp);
     if (sp.shift <= FINE_MAX_SHIFT)
-        hipLaunchKernelGGL(fine_sort_kernel<FINE_MAX_SHIFT>, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp,
-                           sp, table, cell_start, sorted, sorted3, d_nonempty);
-    else
-        hipLaunchKernelGGL(fine_sort_kernel<FINE_BIG_SHIFT>, dim3(sp.nb), dim3(GB_THREADS), 0, ctx->stream, tmp,
-                           sp, table, cell_start, sorted, sorted3, d_nonempty);
+        hipLaunchKernelGGL((fine_sort_kernel<FINE_MAX_SHIFT, GB_THREADS>), dim3(sp.nb), dim3(GB_THREADS), 0,
+                           ctx->stream, tmp, sp, table, cell_start, sorted, sorted3, d_nonempty);
+    else  // one block per CU (its counters fill the LDS): sixteen waves instead of four
+        hipLaunchKernelGGL((fine_sort_kernel<FINE_BIG_SHIFT, 1024>), dim3(sp.nb), dim3(1024), 0, ctx->stream,
+                           tmp, sp, table, cell_start, sorted, sorted3, d_nonempty);
     PCRS_HIP_CHECK(ctx, hipGetLastError());
     return PCRS_OK;
 }

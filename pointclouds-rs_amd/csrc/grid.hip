@@ -3964,11 +3964,14 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     // those go first, on the context's stream, while the finer grids run beside them; what the
     // finer grids hand to it is a second, small pass behind them.  (Not when the caller wants the
     // uncertified queries back as one list and this grid is the last: two passes, two lists.)
-    // Nor for clouds of tens of millions of points: their finer grids are many and large enough to
-    // fill the GPU between them, and the second pass costs a scan of this grid's slots (100 M
-    // points: 49 ms without the split, 53 ms with it; 24 M: 15.1 / 14.2 ms; the 200 K-point blob,
-    // whose chain of finer grids is hidden behind this grid's own queries: 4.8 / 3.45 ms).
-    const bool split = side && !(order[top_pos].next < 0 && q.no_brute) && top->nvalid <= (32u << 20);
+    // (The second pass costs a scan of this grid's slots: 100 M points 43.5 -> 42.9 ms with it,
+    // 48 M 27.0 -> 25.7 ms, 24 M 15.1 -> 14.2 ms; the 200 K-point blob, whose chain of finer grids
+    // is hidden behind this grid's own queries: 4.8 -> 3.45 ms.)
+    static const size_t split_max = [] {  // experiments only: PCRS_GRID_SPLIT_MAX=<points>
+        const char *e = getenv("PCRS_GRID_SPLIT_MAX");
+        return e ? (size_t)atoll(e) : ~(size_t)0;
+    }();
+    const bool split = side && !(order[top_pos].next < 0 && q.no_brute) && top->nvalid <= split_max;
     std::vector<int> lane_of(order.size(), 0);  // 0: the context's stream, 1..: a side stream
     std::vector<std::vector<int>> under(order.size());
     hipStream_t const main_stream = ctx->stream;

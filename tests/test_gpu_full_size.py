@@ -140,8 +140,9 @@ def test_clustered_3m_sampled_parity():
 
 
 @pytest.mark.timeout(600)
-def test_survey_scene_24m_sampled_parity():
-    """The survey scene of the benchmark's second c4 line at 24 M points (terrain, roofs, walls,
+@pytest.mark.parametrize("scale", [10.0, 41.4937759], ids=["24m", "100m"])
+def test_survey_scene_sampled_parity(scale):
+    """The survey scene of the benchmark's second c4 line at 24 M and at its 100 M points (terrain, roofs, walls,
     canopies, trunks): the index gives the crowded regions finer grids of their own, searches them
     side by side on streams of its own, and answers its own queries beside them.  Samples of the
     means from every kind of surface against the brute-force kernel, on two builds in a row (the
@@ -153,7 +154,7 @@ def test_survey_scene_24m_sampled_parity():
 
     eng = HipEngine.shared(0)
     k = 16
-    *cols_h, parts = synth.aerial_scene(10.0, 42, with_parts=True)
+    *cols_h, parts = synth.aerial_scene(scale, 42, with_parts=True)
     n = len(cols_h[0])
     cols = [eng.from_numpy(c) for c in cols_h]
     del cols_h

@@ -564,6 +564,10 @@ struct SlotChoice {
     const uint8_t *handed;
     uint8_t level;
     bool no_own;
+    // (nullable) the same bytes, writable: a pass that only takes what it is handed and runs
+    // before everybody has marked their queries strikes out (0xFF, no level's number) what it
+    // takes, so that the pass after the late-comers does not take it again
+    uint8_t *consume;
 };
 // The test itself, for one sorted slot.
 __device__ __forceinline__ bool slot_is_query(const SlotChoice &ch, const float4 &p) {
@@ -1825,7 +1829,10 @@ __global__ __launch_bounds__(GB_THREADS) void owned_write_kernel(const float4 *s
     for (int w = 0; w < wave; ++w) at += wsum[w];
 #pragma unroll
     for (int i = 0; i < OWN_PER_THREAD; ++i)
-        if (f & (1u << i)) list[at++] = first + i;
+        if (f & (1u << i)) {
+            list[at++] = first + i;
+            if (ch.consume) ch.consume[__float_as_uint(spts[first + i].w)] = 0xFFu;
+        }
 }
 
 // 1-NN retry of ONE query by a whole wave (the K = 1 case of knn_wave_kernel as a function, see
@@ -3781,10 +3788,14 @@ static void launch_wave_kernel(pcrs_ctx *ctx, const CellArgs &a, const KnnOut &o
 // number into *d_count (device).  Count per block of 1024 slots, scan, ordered write.
 static int choose_slots(pcrs_index *ix, const SlotChoice &ch, uint32_t *list, uint32_t *d_count) {
     pcrs_ctx *ctx = ix->ctx;
-    DevBuf own_counts, own_sums;
+    // (kept with the index: a buffer given back here could be handed, while these kernels are
+    // still queued, to a grid of the same index that runs on another stream)
+    DevBuf &own_counts = ix->slot_counts, &own_sums = ix->slot_sums;
     const uint32_t oblocks = (uint32_t)((ix->nvalid + OWN_BLOCK - 1) / OWN_BLOCK);
-    PCRS_HIP_CHECK(ctx, own_counts.alloc(ctx, ((size_t)oblocks + 8) * sizeof(uint32_t)));
-    PCRS_HIP_CHECK(ctx, own_sums.alloc(ctx, ((size_t)oblocks / 1024 + 4) * sizeof(uint32_t)));
+    if (own_counts.bytes < ((size_t)oblocks + 8) * sizeof(uint32_t))
+        PCRS_HIP_CHECK(ctx, own_counts.alloc(ctx, ((size_t)oblocks + 8) * sizeof(uint32_t)));
+    if (own_sums.bytes < ((size_t)oblocks / 1024 + 4) * sizeof(uint32_t))
+        PCRS_HIP_CHECK(ctx, own_sums.alloc(ctx, ((size_t)oblocks / 1024 + 4) * sizeof(uint32_t)));
     hipLaunchKernelGGL(owned_count_kernel, dim3(oblocks), dim3(GB_THREADS), 0, ctx->stream,
                        ix->spts.as<float4>(), (uint32_t)ix->nvalid, ch, own_counts.as<uint32_t>());
     PCRS_TRY(pcrs_launch_scan_u32(ctx, own_counts.as<uint32_t>(), oblocks, own_sums.as<uint32_t>(),
@@ -3928,7 +3939,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         if (l.next >= 0) is_target[(size_t)l.next] = true;
     size_t top_pos = 0;
     while (order[top_pos].ix != top) ++top_pos;
-    std::vector<SlotChoice> choices(order.size() + 1);
+    std::vector<SlotChoice> choices(2 * order.size());
     for (size_t li = 0; li < order.size(); ++li) {
         const Level &lv = order[li];
         SlotChoice ch{};
@@ -3943,8 +3954,10 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         ch.level = (uint8_t)li;
         choices[li] = ch;
     }
-    choices[order.size()] = choices[top_pos];  // the index's own grid without what it is handed
-    choices[order.size()].handed = nullptr;
+    for (size_t li = 0; li < order.size(); ++li) {  // every grid without what it is handed
+        choices[order.size() + li] = choices[li];
+        choices[order.size() + li].handed = nullptr;
+    }
     if (!top->level_choices.p) {  // the levels of an index never change: uploaded once
         PCRS_HIP_CHECK(ctx, top->level_choices.alloc(ctx, choices.size() * sizeof(SlotChoice)));
         PCRS_HIP_CHECK(ctx, hipMemcpyAsync(top->level_choices.p, choices.data(), choices.size() * sizeof(SlotChoice),
@@ -4022,7 +4035,8 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
     uint32_t *level_stats = top->level_stats.as<uint32_t>();
     const uint32_t *esc_list = nullptr, *esc_count = nullptr;  // what the last level left
     // One level's stages.  mode 0: its own queries and what it is handed; 1: its own only (waits
-    // for nobody); 2: only what it is handed.
+    // for nobody); 2: only what it is handed; 3: what it has been handed so far, struck out as it
+    // is taken (another pass of the level follows).
     auto run_level = [&](size_t li, int mode) -> int {
         const Level &lv = order[li];
         pcrs_index *ix = lv.ix;
@@ -4070,6 +4084,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         if (!filtered) {
             SlotChoice ch = choices[li];
             if (mode == 2) ch.no_own = true;
+            if (mode == 3) ch.consume = hand;
             PCRS_TRY(choose_slots(ix, ch, listS, &counters[4]));
         }
 
@@ -4119,7 +4134,7 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         if (filtered) {
             a.qmode = 5;
             a.nq = (uint32_t)ix->nvalid;
-            a.choice = top->level_choices.as<SlotChoice>() + (mode == 1 ? order.size() : li);
+            a.choice = top->level_choices.as<SlotChoice>() + (mode == 1 ? order.size() + li : li);
         } else {
             a.qmode = 3;
             a.qlist = listS;
@@ -4162,14 +4177,14 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         ix->left_count = &counters[3];
         esc_list = listB;
         esc_count = &counters[3];
-        if (mode == 1 && last_level) {
+        if ((mode == 1 || mode == 3) && last_level) {
             // nothing comes after this grid: what its own queries leave is answered here and now,
             // before the second pass takes the lists
             PCRS_TRY(pcrs_launch_knn_bf(ctx, top->x, top->y, top->z, top->m, q, out, kneed, esc_list, esc_count,
                                         m));
         }
         ctx->timing = timing_was;
-        if (side && li < top_pos && lane_of[(size_t)lv.next] != lane_of[li])
+        if (side && mode != 1 && li < top_pos && lane_of[(size_t)lv.next] != lane_of[li])
             PCRS_HIP_CHECK(ctx, hipEventRecord(ctx->level_events[li], ctx->stream));
         static const bool debug = getenv("PCRS_GRID_DEBUG") != nullptr;  // experiments only
         if (debug) {
@@ -4184,7 +4199,17 @@ static int launch_knn_levels(pcrs_index *top, const KnnQuery &q, const KnnOut &o
         return PCRS_OK;
     };
     if (split) PCRS_TRY(run_level(top_pos, 1));
-    for (size_t li = 0; li < order.size(); ++li) PCRS_TRY(run_level(li, split && li == top_pos ? 2 : 0));
+    // ... and the coarser grid behind it takes what those leave it right away, beside the finer
+    // grids, instead of after everything (what the second pass hands it is a pass of its own)
+    const bool early_coarse = split && order[top_pos].next >= 0;
+    if (early_coarse) PCRS_TRY(run_level((size_t)order[top_pos].next, 3));
+    // (The same one level down -- every grid with finer grids under it running its own queries
+    // beside them -- was tried: the blob's chain of three 3.1 -> 2.8 ms, but the ring scan
+    // 1.56 -> 1.68 ms and the survey scenes 1-3 % slower: a second pass is a compaction and a
+    // wave-kernel lifetime more per grid.)
+    std::vector<bool> two_passes(order.size(), false);
+    if (split) two_passes[top_pos] = true;
+    for (size_t li = 0; li < order.size(); ++li) PCRS_TRY(run_level(li, two_passes[li] ? 2 : 0));
     // what even the coarsest level (no open faces) could not certify: more ties than a wave lists
     ctx->stream = main_stream;  // every side stream has been waited for by the grid above its grids
     rejoin.armed = false;

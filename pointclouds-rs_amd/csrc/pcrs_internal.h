@@ -240,6 +240,7 @@ struct pcrs_index {
     // a byte per point of the columns, for a search over the chain of grids: the level a query
     // that one level could not answer is meant for next
     DevBuf hand_flags;
+    DevBuf slot_counts, slot_sums;  // scratch of the compaction of this grid's query slots
     DevBuf level_stats;    // what the last search over the levels reports (16 words)
     DevBuf level_choices;  // the query test of every level (grid.hip: SlotChoice), in the order they run
     double aim = 0.0;  // points per occupied cell the build aimed at

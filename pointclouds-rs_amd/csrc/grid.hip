@@ -309,7 +309,7 @@ __global__ __launch_bounds__(GB_THREADS) void scatter_kernel(const float *x, con
 }
 
 // ---- two-level counting sort by cell (no global atomics)
-// Level 1 splits the cloud into <= 8192 (16384 for the very largest grids) coarse buckets of
+// Level 1 splits the cloud into <= 8192 (16128 for the very largest grids) coarse buckets of
 // 2^shift consecutive cells with per-block
 // LDS histograms (bucket-major table of per-block counts -> exclusive scan -> per-block write
 // cursors).  Level 2 gives every bucket to one block, which histograms its 2^shift cells in LDS,
@@ -2572,7 +2572,7 @@ void make_geometry(const double lo[3], const double ext[3], double emax, double 
     *cell_used = cell;
 }
 
-// Shape of the two-level sort for this grid; false when the grid has more cells than 16384 coarse
+// Shape of the two-level sort for this grid; false when the grid has more cells than 16128 coarse
 // buckets of 2^15 (the global-atomic counting sort handles those).
 // m: points in the columns; n_taken: how many of them the sort will place (fewer when the index
 // covers a box of the cloud): the buckets are sized for those, the blocks of level 1 share out m.
@@ -2587,9 +2587,9 @@ bool plan_sort(const GridGeom &g, uint32_t ncell, uint32_t m, SortPlan *sp, uint
     uint32_t nb_max = 1024u;
     if (n_taken / 1536u > nb_max) nb_max = n_taken / 1536u < 8192u ? n_taken / 1536u : 8192u;
     if (ncell > (nb_max << FINE_MAX_SHIFT)) nb_max = 8192u;
-    // (beyond 8192 buckets of 2^15 cells: 16384 buckets, all the 64 KB of histogram a level-1
+    // (beyond 8192 buckets of 2^15 cells: 16128 buckets, 63 of the 64 KB of histogram a level-1
     // block can have without asking for more)
-    if (ncell > (8192u << FINE_BIG_SHIFT)) nb_max = 16384u;
+    if (ncell > (8192u << FINE_BIG_SHIFT)) nb_max = 16128u;
     uint32_t shift = 0;
     while (((ncell + (1u << shift) - 1) >> shift) > nb_max) ++shift;
     if (shift > FINE_BIG_SHIFT) return false;

@@ -201,7 +201,7 @@ int finish_index(pcrs_index *ix, uint32_t k_hint, int algo) {
 }  // namespace
 
 int pcrs_index_build_hinted_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
-                                size_t m, uint32_t k_hint, pcrs_index **out) {
+                                size_t m, uint32_t k_hint, pcrs_index **out, const double *bounds) {
     *out = nullptr;
     pcrs_index *ix = new (std::nothrow) pcrs_index();
     if (!ix) return pcrs_set_err(ctx, PCRS_ERR_OOM, "host allocation failed");
@@ -212,6 +212,15 @@ int pcrs_index_build_hinted_dev(pcrs_ctx *ctx, const float *dx, const float *dy,
     ix->m = m;
     ix->k_hint = k_hint;
     ix->use_hint = true;
+    if (bounds && std::isfinite(bounds[0] + bounds[1] + bounds[2] + bounds[3] + bounds[4] + bounds[5])) {
+        ix->have_bounds = true;
+        ix->bounds_count_exact = true;
+        ix->bounds_n_upper = m;
+        for (int a = 0; a < 3; ++a) {
+            ix->bounds_lo[a] = bounds[a];
+            ix->bounds_hi[a] = bounds[3 + a];
+        }
+    }
     const int rc = finish_index(ix, k_hint, PCRS_ALGO_AUTO);
     if (rc != PCRS_OK) {
         delete ix;

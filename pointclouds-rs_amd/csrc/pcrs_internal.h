@@ -359,13 +359,16 @@ struct PcrsCellSort {
     const uint32_t *order = nullptr;  // [nvalid] point index at each sorted position
     const uint32_t *d_ncells = nullptr;  // device: number of occupied cells
     uint32_t nvalid = 0;          // finite points
+    int key_lo[3] = {0, 0, 0}, key_hi[3] = {0, 0, 0};  // smallest and largest key per axis (nvalid > 0)
 };
 int pcrs_cell_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z, size_t n,
                    float scale, bool multiply, PcrsCellSort *cs);
 // voxel_downsample on device columns (voxel.hip); ox/oy/oz hold up to n centroids.
+// bounds (nullable, [6]: lo x y z, hi x y z): a box that holds every centroid, from the voxel keys
+// the sort has to know anyway; left untouched (NaN in, NaN out) where the keys saturate.
 int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                                  size_t n, float voxel_size, float *ox, float *oy, float *oz,
-                                 size_t *n_out);
+                                 size_t *n_out, double *bounds = nullptr);
 // Plane RANSAC behind its sample generation (ransac.hip): d_samples holds ns index triples,
 // d_mask receives the inlier mask of the chosen plane.  The call waits for the stream (its results
 // are host values); h_mask_out (nullable, host memory) receives a copy of the mask before that
@@ -518,8 +521,11 @@ int pcrs_launch_select_result(pcrs_ctx *ctx, const void *d_scalars,
 // pcrs_index_build_dev for a caller that feeds one cloud after another of the same kind from
 // device memory (the frames of a sensor): the build starts from the geometry the context's last
 // build ended with (api.cpp)
+// bounds (nullable, [6] as above, all finite): a box that holds all m points, every one of them
+// finite -- the build then skips its pass over the columns and the read-back behind it.
 int pcrs_index_build_hinted_dev(pcrs_ctx *ctx, const float *dx, const float *dy, const float *dz,
-                                size_t m, uint32_t k_hint, pcrs_index **out);
+                                size_t m, uint32_t k_hint, pcrs_index **out,
+                                const double *bounds = nullptr);
 
 // what the multi-GPU driver (dist.cpp) needs to know about an ICP handle (api.cpp)
 pcrs_ctx *pcrs_icp_context(pcrs_icp *icp);

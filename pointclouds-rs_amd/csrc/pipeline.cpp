@@ -95,9 +95,11 @@ extern "C" int pcrs_obstacle_pipeline(pcrs_ctx *ctx, const float *x, const float
     PCRS_TRY(check_hip(ctx, vy.alloc(ctx, nb), "alloc"));
     PCRS_TRY(check_hip(ctx, vz.alloc(ctx, nb), "alloc"));
     size_t nv = 0;
+    // (the voxel keys bound the centroids: the index over them needs no pass for its bounding box)
+    double vbounds[6] = {NAN, NAN, NAN, NAN, NAN, NAN};
     PCRS_TRY(pcrs_launch_voxel_downsample(ctx, dx.as<float>(), dy.as<float>(), dz.as<float>(), n,
                                           prm->voxel_size, vx.as<float>(), vy.as<float>(),
-                                          vz.as<float>(), &nv));
+                                          vz.as<float>(), &nv, vbounds));
     res->n_voxels = nv;
     if (nv == 0) return PCRS_OK;
     // 2. statistical_outlier_removal (statistical_outlier.rs:4-69) -> the kept points, compacted
@@ -115,7 +117,7 @@ extern "C" int pcrs_obstacle_pipeline(pcrs_ctx *ctx, const float *x, const float
     } else {
         pcrs_index *ix = nullptr;
         PCRS_TRY(pcrs_index_build_hinted_dev(ctx, vx.as<float>(), vy.as<float>(), vz.as<float>(), nv,
-                                             prm->sor_k + 1, &ix));
+                                             prm->sor_k + 1, &ix, vbounds));
         DevBuf mean;
         int rc = check_hip(ctx, mean.alloc(ctx, nv * sizeof(float)), "alloc");
         if (rc == PCRS_OK) rc = pcrs_sor_mean_dist_dev(ix, 0, nv, prm->sor_k, mean.as<float>());

@@ -223,6 +223,10 @@ int pcrs_cell_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z
     const uint32_t nvalid = hb->nvalid;
     cs->nvalid = nvalid;
     if (nvalid == 0) return PCRS_OK;
+    for (int a = 0; a < 3; ++a) {
+        cs->key_lo[a] = hb->lo[a];
+        cs->key_hi[a] = hb->hi[a];
+    }
     const int lo[3] = {hb->lo[0], hb->lo[1], hb->lo[2]};
     uint64_t range[3];
     for (int a = 0; a < 3; ++a) range[a] = (uint64_t)((int64_t)hb->hi[a] - (int64_t)lo[a]) + 1u;
@@ -290,12 +294,29 @@ int pcrs_cell_sort(pcrs_ctx *ctx, const float *x, const float *y, const float *z
 
 int pcrs_launch_voxel_downsample(pcrs_ctx *ctx, const float *x, const float *y, const float *z,
                                  size_t n, float voxel_size, float *ox, float *oy, float *oz,
-                                 size_t *n_out) {
+                                 size_t *n_out, double *bounds) {
     *n_out = 0;
     if (n == 0) return PCRS_OK;
     PcrsCellSort cs;
     PCRS_TRY(pcrs_cell_sort(ctx, x, y, z, n, voxel_size, false, &cs));
     if (cs.nvalid == 0) return PCRS_OK;  // voxel_downsample.rs:44-46
+    if (bounds) {
+        // The points of voxel k lie in [k, k + 1) x voxel_size up to the rounding of one division,
+        // and so does their mean up to the rounding of its sums: a thousandth of a voxel and a
+        // millionth of the coordinate on either side cover both.  Keys that saturate (coordinates
+        // beyond 2^30 voxels) bound nothing.
+        bool usable = true;
+        for (int a = 0; a < 3; ++a)
+            usable = usable && cs.key_lo[a] > -(1 << 30) && cs.key_hi[a] < (1 << 30);
+        if (usable)
+            for (int a = 0; a < 3; ++a) {
+                const double lo = (double)cs.key_lo[a] * (double)voxel_size;
+                const double hi = ((double)cs.key_hi[a] + 1.0) * (double)voxel_size;
+                const double slack = 1e-3 * (double)voxel_size + 1e-6 * std::max(std::fabs(lo), std::fabs(hi));
+                bounds[a] = lo - slack;
+                bounds[3 + a] = hi + slack;
+            }
+    }
     const uint32_t nvalid = cs.nvalid;
     hipLaunchKernelGGL(voxel_centroid_kernel, dim3((nvalid + 255) / 256), dim3(256), 0, ctx->stream,
                        cs.flag.as<uint8_t>(), cs.order, cs.cell_id.as<uint32_t>(), nvalid, x, y, z,

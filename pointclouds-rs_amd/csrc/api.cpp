@@ -68,6 +68,22 @@ int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out) {
     return PCRS_OK;
 }
 
+int pcrs_ctx_pinned_io(pcrs_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->pinned_io_bytes) {
+        if (ctx->pinned_io) {
+            PCRS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            PCRS_HIP_CHECK(ctx, hipHostFree(ctx->pinned_io));
+            ctx->pinned_io = nullptr;
+            ctx->pinned_io_bytes = 0;
+        }
+        size_t want = bytes + bytes / 4 + 65536;
+        PCRS_HIP_CHECK(ctx, hipHostMalloc(&ctx->pinned_io, want, hipHostMallocDefault));
+        ctx->pinned_io_bytes = want;
+    }
+    *out = ctx->pinned_io;
+    return PCRS_OK;
+}
+
 hipError_t pcrs_pool_alloc(pcrs_ctx *ctx, size_t bytes, void **p, size_t *cap) {
     // best fit among the free buffers that are not wastefully large
     size_t best = ctx->pool.size();
@@ -287,6 +303,7 @@ void pcrs_ctx_destroy(pcrs_ctx *ctx) try {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_io) (void)hipHostFree(ctx->pinned_io);
     if (getenv("PCRS_POOL_DEBUG")) {  // experiments only
         size_t bytes = 0;
         for (auto &pe : ctx->pool) bytes += pe.bytes;

@@ -27,6 +27,11 @@ struct pcrs_ctx {
     // pinned host staging for small scalar read-backs
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    // a second pinned area for small inputs and results a call moves itself (the kernels'
+    // read-backs land in the first at any time): copies from and to it are queued without the
+    // staging and the wait a copy from pageable memory costs
+    void *pinned_io = nullptr;
+    size_t pinned_io_bytes = 0;
     // reusable device scratch (grown on demand, never shrunk)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -89,6 +94,7 @@ int pcrs_on_exception(pcrs_ctx *ctx) noexcept;
 // grows the context's device scratch / pinned staging; returns PCRS_OK or an error code
 int pcrs_ctx_scratch(pcrs_ctx *ctx, size_t bytes, void **out);
 int pcrs_ctx_pinned(pcrs_ctx *ctx, size_t bytes, void **out);
+int pcrs_ctx_pinned_io(pcrs_ctx *ctx, size_t bytes, void **out);
 
 #define PCRS_TRY(expr)                  \
     do {                                \

@@ -5,6 +5,7 @@
 // in device memory: a frame of 57 K points is bound by the host's copies and waits when each stage
 // takes host buffers in and out.
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <vector>
 
@@ -136,14 +137,17 @@ extern "C" int pcrs_obstacle_pipeline(pcrs_ctx *ctx, const float *x, const float
                                 keep.as<uint8_t>(), 0, cx.as<float>(), cy.as<float>(), cz.as<float>(),
                                 nullptr, nullptr));
     // 3. ransac_plane_seeded (ransac_plane.rs:56-138) over the mirror's sample stream
-    std::vector<uint32_t> triples(3 * (size_t)prm->plane_iterations + 3);
+    // (generated straight into pinned memory: the upload is queued, not staged and waited for)
+    void *io = nullptr;
+    PCRS_TRY(pcrs_ctx_pinned_io(ctx, (3 * (size_t)prm->plane_iterations + 3) * sizeof(uint32_t), &io));
+    uint32_t *triples = reinterpret_cast<uint32_t *>(io);
     size_t ns = 0;
-    PCRS_TRY(pcrs_sample_triples(nk, prm->plane_iterations, prm->plane_seed, triples.data(), &ns));
+    PCRS_TRY(pcrs_sample_triples(nk, prm->plane_iterations, prm->plane_seed, triples, &ns));
     DevBuf dsamples, inl;
     PCRS_TRY(check_hip(ctx, dsamples.alloc(ctx, (3 * ns + 3) * sizeof(uint32_t)), "alloc"));
     PCRS_TRY(check_hip(ctx, inl.alloc(ctx, nk), "alloc"));
     if (ns)
-        PCRS_TRY(check_hip(ctx, hipMemcpyAsync(dsamples.p, triples.data(), 3 * ns * sizeof(uint32_t),
+        PCRS_TRY(check_hip(ctx, hipMemcpyAsync(dsamples.p, triples, 3 * ns * sizeof(uint32_t),
                                                hipMemcpyHostToDevice, st), "upload"));
     size_t n_in = 0;
     uint64_t best = 0;
@@ -178,13 +182,24 @@ extern "C" int pcrs_obstacle_pipeline(pcrs_ctx *ctx, const float *x, const float
                                            dind.as<uint32_t>(), &nc, &ni));
     res->n_clusters = nc;
     res->n_cluster_points = ni;
-    if (cluster_offsets)
-        PCRS_TRY(check_hip(ctx, hipMemcpyAsync(cluster_offsets, doff.p, (nc + 1) * sizeof(uint32_t),
-                                               hipMemcpyDeviceToHost, st), "download"));
-    if (cluster_indices && ni)
-        PCRS_TRY(check_hip(ctx, hipMemcpyAsync(cluster_indices, dind.p, ni * sizeof(uint32_t),
-                                               hipMemcpyDeviceToHost, st), "download"));
+    // the cluster lists come back through pinned memory (two queued copies and one wait; a copy
+    // into the caller's pageable arrays is staged and waited for, each on its own)
+    const size_t noff = cluster_offsets ? nc + 1 : 0, nind = cluster_indices ? ni : 0;
+    uint32_t *back = nullptr;
+    if (noff + nind) {
+        // (the sample triples in this area have been consumed: the plane stage has waited for its result)
+        PCRS_TRY(pcrs_ctx_pinned_io(ctx, (noff + nind) * sizeof(uint32_t), &io));
+        back = reinterpret_cast<uint32_t *>(io);
+        if (noff)
+            PCRS_TRY(check_hip(ctx, hipMemcpyAsync(back, doff.p, noff * sizeof(uint32_t), hipMemcpyDeviceToHost, st),
+                               "download"));
+        if (nind)
+            PCRS_TRY(check_hip(ctx, hipMemcpyAsync(back + noff, dind.p, nind * sizeof(uint32_t),
+                                                   hipMemcpyDeviceToHost, st), "download"));
+    }
     PCRS_TRY(check_hip(ctx, hipStreamSynchronize(st), "stream synchronize"));
+    if (noff) std::memcpy(cluster_offsets, back, noff * sizeof(uint32_t));
+    if (nind) std::memcpy(cluster_indices, back + noff, nind * sizeof(uint32_t));
     return PCRS_OK;
 } catch (...) {
     return pcrs_on_exception(ctx);

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(ROOT, "pointclouds-rs_amd"))
 from pointclouds_rs import hip, synth
 x, y, z = synth.kitti_scene(42)
 ts = []
-for i in range(600):
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 600):
     t0 = time.perf_counter()
     out = hip.obstacle_pipeline(x, y, z, 0.15, 20, 2.0, 0.15, 500, 1234, 0.8, 10, 20000, want_obstacles=False, device=0)
     ts.append((time.perf_counter() - t0) * 1e3)
